@@ -1,0 +1,221 @@
+/*
+ * pgca_hip.h - C ABI of libpgca_hip.so: the MI355X (gfx950) kernels behind the
+ * Stage-1 NT-Xent and Stage-2 DPO steps of preference-guided captioning alignment.
+ *
+ * The reference (A-SHOJAEI/preference-guided-image-captioning-alignment) is 100 %
+ * Python: it has no FFI of its own.  Its seam for this path is the Python surface
+ * (models/model.py, models/components.py, training/trainer.py); each entry point
+ * below names the reference call site whose ATen/cuBLAS/SDPA launches it replaces.
+ * The binding a maintainer adds on the reference side is a ctypes stub - see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     stated otherwise; buffers are caller-owned (the Python host allocates them
+ *     with torch's caching allocator and passes tensor.data_ptr()).
+ *   - `stream` is a hipStream_t passed as void*; kernels are asynchronous on it,
+ *     never allocate, never synchronise, keep no global mutable state except the
+ *     thread-local last-error string.
+ *   - bf16 = IEEE bfloat16 stored as uint16_t; f32 accumulation everywhere.
+ *   - token ids / targets are int64 exactly as the reference supplies them.
+ *   - return value: 0 on success, negative pgca_status otherwise.
+ */
+#ifndef PGCA_HIP_H
+#define PGCA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum pgca_status {
+  PGCA_OK = 0,
+  PGCA_ERR_INVALID = -1, /* bad shape / alignment / null pointer */
+  PGCA_ERR_LAUNCH = -2   /* hipLaunch failed; see pgca_last_error() */
+} pgca_status;
+
+int pgca_version(void);
+const char* pgca_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM (MFMA bf16) */
+/* Operand layouts.  "K" is the contraction dimension.
+ *   PGCA_NT: A[M,K] row-major, B[N,K] row-major   (nn.Linear forward; dgrad through Conv1D)
+ *   PGCA_NN: A[M,K] row-major, B[K,N] row-major   (GPT-2 Conv1D forward; dgrad through nn.Linear)
+ *   PGCA_TN: A[K,M] row-major, B[K,N] row-major   (every weight gradient: X^t dY)
+ * Constraints: lda/ldb multiples of 8 elements, base pointers 16-B aligned; for
+ * operands whose contiguous dimension is K (A in NT/NN, B in NT) K % 8 == 0. */
+enum { PGCA_NT = 0, PGCA_NN = 1, PGCA_TN = 2 };
+
+/* Epilogues, applied to v = alpha*acc (+ bias[n]). */
+enum {
+  PGCA_EPI_NONE = 0,
+  PGCA_EPI_GELU_NEW = 1,   /* GPT-2 MLP (modeling_gpt2.py:229-243); aux_out (opt.) <- pre-activation */
+  PGCA_EPI_QUICK_GELU = 2, /* CLIP MLP (activations.py:117-123) */
+  PGCA_EPI_RELU = 3,       /* projection heads (model.py:138,340) */
+  PGCA_EPI_TANH = 4,       /* vision_projection (model.py:523) */
+  PGCA_EPI_DGELU_NEW = 5,  /* v *= gelu_new'(aux_in[m,n]) (aux_in = saved pre-activation) */
+  PGCA_EPI_DRELU = 6,      /* v *= aux_in[m,n] > 0       (aux_in = saved activation) */
+  PGCA_EPI_DTANH = 7,      /* v *= 1 - aux_in[m,n]^2     (aux_in = saved activation) */
+  PGCA_EPI_ROWSTATS = 8,   /* no C written: per-row partial (max, sum exp) over this block's columns
+                              + target-logit pick; fused LM head / NT-Xent (model.py:1069-1079,988-998) */
+  PGCA_EPI_DLOGITS = 9     /* v = row_scale[m] * (exp(v - row_lse[m]) - (n == target[m])); 0 for n >= N */
+};
+
+typedef struct pgca_gemm_args {
+  const void* A;  /* bf16 */
+  const void* B;  /* bf16 */
+  int32_t M, N, K;
+  int32_t lda, ldb;
+  int32_t layout;
+  int32_t epilogue;
+  float alpha;            /* scale on the accumulator (1/tau for NT-Xent) */
+  const float* bias;      /* [N] f32 or NULL */
+  void* out_bf16;         /* [M, ld_out_bf16] or NULL */
+  int32_t ld_out_bf16;
+  float* out_f32;         /* [M, ld_out_f32] or NULL */
+  int32_t ld_out_f32;
+  int32_t accumulate;     /* out_f32 += v instead of = v (gradient accumulation) */
+  const float* residual;  /* [M, ld_res] f32 added to v before the store, or NULL */
+  int32_t ld_res;
+  void* aux_out;          /* bf16 [M, ld_aux]: pre-activation written by *_GELU epilogues, or NULL */
+  const void* aux_in;     /* bf16 [M, ld_aux]: operand of the D* epilogues */
+  int32_t ld_aux;
+  /* ROWSTATS / DLOGITS */
+  const int64_t* targets; /* [M] column index per row, or NULL (NT-Xent: diagonal given explicitly) */
+  float* stat_max;        /* [M, stat_ld]  partial row max   (ROWSTATS) */
+  float* stat_sum;        /* [M, stat_ld]  partial sum exp(v - max) */
+  int32_t stat_ld;        /* >= 2 * ceil(N / 128) */
+  float* target_val;      /* [M] v at the target column (ROWSTATS) */
+  const float* row_lse;   /* [M] (DLOGITS) */
+  const float* row_scale; /* [M] (DLOGITS) */
+  int32_t out_cols;       /* DLOGITS: columns written (>= N, padding columns get 0) */
+} pgca_gemm_args;
+
+int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
+
+/* Per-row combine of ROWSTATS partials: lse[m] = log sum exp over all columns;
+ * out_logprob[m] = target_val[m] - lse[m] (token log-prob, reference model.py:1074-1079). */
+int pgca_rowstats_combine(const float* stat_max, const float* stat_sum, int32_t stat_ld, int32_t nparts,
+                          const float* target_val, int32_t M, float* lse, float* out_logprob, void* stream);
+
+/* ------------------------------------------------------------------ LayerNorm */
+/* y = LN(x) * gamma + beta, eps as given (1e-5 everywhere in the reference).
+ * x f32 [rows_in, H]; optional row_map[M] gathers rows (y row m <- x row row_map[m]);
+ * y_bf16 / y_f32 [M, H] (either may be NULL); mean/rstd [M] saved for backward (may be NULL).
+ * Replaces F.layer_norm at model.py:141,343,535,601 and HF ln_1/ln_2/ln_f, CLIP layer_norm*. */
+int pgca_layernorm_fwd(const float* x, const int32_t* row_map, int32_t M, int32_t H, const float* gamma,
+                       const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
+                       void* stream);
+
+/* dx = LN backward; dy given as bf16 (dy_bf16) or f32 (dy_f32), exactly one non-NULL.
+ * dx_out[row] = (add_to ? add_to[row] : 0) + dx   with row = row_map ? row_map[m] : m.
+ * dx_bf16 (optional) receives the same value rounded to bf16 (operand of the next dgrad GEMM).
+ * dgamma/dbeta partial sums go to part[2, nblk, H] (nblk returned by pgca_layernorm_bwd_blocks);
+ * pgca_colsum_finish folds them into the gradient buffers. */
+int pgca_layernorm_bwd_blocks(int32_t M);
+int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
+                       int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
+                       const float* add_to, float* dx_out, void* dx_bf16, float* part, void* stream);
+/* out[h] (+)= sum_b part[b, h]; nparts rows of length H. */
+int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, float* out, int32_t accumulate, void* stream);
+
+/* Column sums of a bf16 / f32 matrix (bias gradients): out[n] (+)= sum_m x[m, n]. */
+int pgca_colsum_blocks(int32_t M);
+int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, int32_t ld, float* part, void* stream);
+
+/* ------------------------------------------------------------------ attention (head_dim 64) */
+/* qkv bf16 [B*S, 3*H] (q | k | v, head h at columns h*64), out bf16 [B*S, H], lse f32 [B, heads, S].
+ * softmax(q k^t / 8 + mask) v with mask = causal AND key_mask[b, key] != 0 (key_mask int32 [B,S] or NULL).
+ * S <= 128.  Replaces SDPA at modeling_gpt2.py:54-72,203-215 and modeling_clip.py:259-277. */
+int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int32_t B, int32_t S, int32_t heads,
+                       int32_t causal, void* out, float* lse, void* stream);
+/* dqkv bf16 [B*S, 3*H] from dout bf16 [B*S, H], the saved qkv / out / lse. */
+int pgca_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                       const int32_t* key_mask, int32_t B, int32_t S, int32_t heads, int32_t causal,
+                       void* dqkv, void* stream);
+
+/* ------------------------------------------------------------------ embeddings */
+/* Caption-decoder input (reference model.py:591-601 + modeling_gpt2.py:571-577):
+ *   e = wte[ids[b,s]] + attended[b]; x = LN(e; attention_norm); h0[b,s] = x + wpe[s]
+ * attended[b] = W_o(W_v pv_b + b_v) + b_o is the collapsed 1-key cross-attention.
+ * Text tower (modeling_gpt2.py:568-577): attended == NULL and gamma == NULL -> h0 = wte[id] + wpe[s].
+ * mean/rstd [B*S] saved when LN is applied. ids int64. */
+int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t H, const float* wte, const float* wpe,
+                   const float* attended, const float* gamma, const float* beta, float eps, float* h0,
+                   float* mean, float* rstd, void* stream);
+/* Backward of the above given g = dL/dh0 [B*S, H] (f32):
+ *   dwpe[s] += sum_b g; through LN (if gamma) -> de; dwte[ids] += de (rows with row_mask==0 skipped:
+ *   their gradient is exactly zero); dattended[b] = sum_s de; dgamma/dbeta partials in part[2,nblk,H]. */
+int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t* row_mask, int32_t B, int32_t S, int32_t H,
+                   const float* wte, const float* attended, const float* gamma, const float* mean,
+                   const float* rstd, float* dwte, float* dwpe, float* dattended, float* part, void* stream);
+int pgca_embed_bwd_blocks(int32_t B, int32_t S);
+
+/* ViT patch gather (modeling_clip.py:200-218): pixels f32 [B,3,I,I] -> bf16 [B*G*G, 3*P*P] in the
+ * (c, ky, kx) order of the conv weight, so the bias-free Conv2d is one NT GEMM. */
+int pgca_patchify(const float* pixels, int32_t B, int32_t image, int32_t patch, void* out_bf16, void* stream);
+/* x[b, 0] = cls + pos[0]; x[b, 1+p] = patches[b, p] + pos[1+p]  (f32 [B, T, H]). */
+int pgca_vit_assemble(const float* patch_embeds, const float* cls, const float* pos, int32_t B, int32_t T,
+                      int32_t H, float* x, void* stream);
+
+/* ------------------------------------------------------------------ sequence reduce + losses */
+/* tok_lp f32 [nrows] are token log-probs of the COMPACT rows; row r belongs to sequence seq_of_row[r].
+ * seq_lp[q] = sum (mode 0; components.py:357-362) or mean over the sequence's scored tokens
+ * (mode 1; model.py:1082-1083; 0/0 = NaN when a caption has <= 1 real token, as the reference). */
+int pgca_seq_reduce(const float* tok_lp, const int32_t* seq_of_row, int32_t nrows, int32_t nseq,
+                    const int32_t* seq_count, int32_t mode, float* seq_lp, void* stream);
+/* DPO / preference loss over B pairs (components.py:210-231, model.py:1047-1048).
+ * pol_w/pol_l/ref_w/ref_l f32 [B] (ref_* may be NULL = reference-free).
+ * loss[0] = mean loss; dpol_w/dpol_l [B] = dLoss/dpol (f32); metrics[4] = reward_margin,
+ * reward_accuracy, mean pol_w, mean pol_l (components.py:234-247), all on device (no host sync). */
+int pgca_dpo_loss(const float* pol_w, const float* pol_l, const float* ref_w, const float* ref_l, int32_t B,
+                  float beta, float label_smoothing, float* loss, float* dpol_w, float* dpol_l, float* metrics,
+                  void* stream);
+/* row_scale[r] = dseq[seq_of_row[r]] * (mode ? 1/count : 1): dLoss/d tok_lp per compact row. */
+int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,
+                   int32_t mode, float* row_scale, void* stream);
+
+/* ------------------------------------------------------------------ pooling / normalise (Stage 1) */
+/* pooled[b] = sum_s feats[b,s]*mask[b,s] / max(sum_s mask, 1)  (model.py:449-456); feats f32. */
+int pgca_masked_mean_fwd(const float* feats, const int32_t* mask, int32_t B, int32_t S, int32_t H, float* pooled,
+                         void* stream);
+int pgca_masked_mean_bwd(const float* dpooled, const int32_t* mask, int32_t B, int32_t S, int32_t H,
+                         float* dfeats, void* stream);
+/* y = x / max(||x||, 1e-12) (F.normalize, model.py:828-829) and its backward. */
+int pgca_l2norm_fwd(const float* x, int32_t B, int32_t P, float* y, float* norm, void* stream);
+int pgca_l2norm_bwd(const float* dy, const float* y, const float* norm, int32_t B, int32_t P, float* dx,
+                    void* stream);
+/* NT-Xent pieces (model.py:988-998) on top of two ROWSTATS GEMMs (rows of S and rows of S^t):
+ * loss[0] = (sum_i (lse_r[i] - diag[i]) + sum_i (lse_c[i] - diag[i])) / (2 * n_total) over n_local rows. */
+int pgca_ntxent_loss(const float* lse_r, const float* lse_c, const float* diag, int32_t n_local, int32_t n_total,
+                     float* loss, void* stream);
+
+/* ------------------------------------------------------------------ optimiser (fused, flat buffers) */
+/* Partial sums of squares of a flat f32 gradient buffer: part[blocks]; blocks = pgca_sqnorm_blocks(n). */
+int pgca_sqnorm_blocks(int64_t n);
+int pgca_sqnorm(const float* g, int64_t n, float* part, void* stream);
+/* Device-side step control (no host sync): reads the partial sums of all segments, derives
+ *   total_norm, finite flag, clip = min(1, max_norm/(norm+1e-6)) (clip_grad_norm_, trainer.py:511-515,619-623),
+ * and - if finite - advances ctrl.step and evaluates the cosine warm-up lr (trainer.py:285-289).
+ * ctrl layout (f32[8]): [0] total_norm [1] finite(1/0) [2] clip [3] lr [4] bias_corr1 [5] bias_corr2
+ *                       [6] opt_step (as float) [7] sched_step (as float). */
+int pgca_step_control(const float* part, int32_t nparts, float max_norm, float base_lr, int32_t warmup,
+                      int32_t total_steps, int32_t sched_stride, float beta1, float beta2, float grad_scale,
+                      float* ctrl, void* stream);
+/* AdamW (trainer.py:275-281: decoupled decay on every parameter) over a flat segment, gradient scaled by
+ * ctrl.clip * grad_scale, skipped entirely when ctrl.finite == 0; refreshes the bf16 mirror. */
+int pgca_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* ctrl,
+               float weight_decay, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* f32 -> bf16 cast of a flat buffer (initial mirror / reference-policy snapshot). */
+int pgca_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+/* y (+)= alpha * x on flat f32 buffers (gradient un-scaling after all-reduce etc.). */
+int pgca_axpy(const float* x, float alpha, float* y, int64_t n, int32_t accumulate, void* stream);
+/* gather / scatter rows of an f32 or bf16 [*, H] matrix by int32 row_map. */
+int pgca_gather_rows_bf16(const void* src, const int32_t* row_map, int32_t M, int32_t H, void* dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGCA_HIP_H */

@@ -1,0 +1,478 @@
+// LayerNorm forward/backward, decoder/text embedding (+LN) forward/backward, column sums.
+// HBM-bound row kernels: one 64-lane wave per row, 16-B loads, statistics in registers
+// (two-pass mean / centred variance like F.layer_norm), gamma/beta gradients reduced
+// per block in registers -> LDS -> one partial row per block (no atomics).
+#include "common.h"
+
+using namespace pgca;
+
+namespace {
+
+constexpr int MAXV = 8;  // float4 per lane -> H <= 2048
+
+struct RowVec {
+  float4 v[MAXV];
+};
+
+template <int NV>
+__device__ __forceinline__ void load_row_f32(const float* __restrict__ p, int H, int lane, float4 (&v)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    v[j] = c < H ? *reinterpret_cast<const float4*>(p + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+template <int NV>
+__device__ __forceinline__ void load_row_bf16(const bf16_t* __restrict__ p, int H, int lane, float4 (&v)[NV]) {
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < H) {
+      bf16x4 t = *reinterpret_cast<const bf16x4*>(p + c);
+      v[j] = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+    } else {
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+__device__ __forceinline__ void store_bf16x4(bf16_t* p, float4 v) {
+  bf16x4 t;
+  t[0] = (bf16_t)v.x;
+  t[1] = (bf16_t)v.y;
+  t[2] = (bf16_t)v.z;
+  t[3] = (bf16_t)v.w;
+  *reinterpret_cast<bf16x4*>(p) = t;
+}
+
+template <int NV>
+__device__ __forceinline__ void row_stats(const float4 (&v)[NV], int H, int lane, float eps, float& mean,
+                                          float& rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += v[j].x + v[j].y + v[j].z + v[j].w;
+  mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < H) {
+      const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+      q += a * a + b * b + cc * cc + d * d;
+    }
+  }
+  rstd = rsqrtf(wave_sum(q) / (float)H + eps);
+}
+
+// ------------------------------------------------------------------------------------ LN forward
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const int* __restrict__ row_map,
+                                                     int M, int H, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps,
+                                                     bf16_t* __restrict__ yb, float* __restrict__ yf,
+                                                     float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const size_t src = row_map ? (size_t)row_map[m] : (size_t)m;
+  float4 v[NV];
+  load_row_f32<NV>(x + src * H, H, lane, v);
+  float mean, rstd;
+  row_stats<NV>(v, H, lane, eps, mean, rstd);
+  if (lane == 0) {
+    if (mean_o) mean_o[m] = mean;
+    if (rstd_o) rstd_o[m] = rstd;
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < H) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+      const float4 b = *reinterpret_cast<const float4*>(beta + c);
+      float4 y;
+      y.x = (v[j].x - mean) * rstd * g.x + b.x;
+      y.y = (v[j].y - mean) * rstd * g.y + b.y;
+      y.z = (v[j].z - mean) * rstd * g.z + b.z;
+      y.w = (v[j].w - mean) * rstd * g.w + b.w;
+      if (yf) *reinterpret_cast<float4*>(yf + (size_t)m * H + c) = y;
+      if (yb) store_bf16x4(yb + (size_t)m * H + c, y);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ LN backward
+// Shared tail: reduce the per-lane dgamma/dbeta accumulators of the block's 4 waves through LDS and
+// write one partial row per block: part[0][blk][H] (dgamma), part[1][blk][H] (dbeta).
+template <int NV>
+__device__ __forceinline__ void write_partials(float4 (&dg)[NV], float4 (&db)[NV], int H, float* __restrict__ part,
+                                               int nblk, float* red /* [2][4][NV*256] */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    *reinterpret_cast<float4*>(red + ((0 * 4 + w) * NV + j) * 256 + lane * 4) = dg[j];
+    *reinterpret_cast<float4*>(red + ((1 * 4 + w) * NV + j) * 256 + lane * 4) = db[j];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 2 * NV * 256; idx += 256) {
+    const int which = idx / (NV * 256), c = idx % (NV * 256);
+    if (c < H) {
+      float s = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) s += red[(which * 4 + ww) * NV * 256 + c];
+      part[((size_t)which * nblk + blockIdx.x) * H + c] = s;
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, const float* __restrict__ dyf,
+                                                     const float* __restrict__ x, const int* __restrict__ row_map,
+                                                     int M, int H, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                     const float* __restrict__ add_to, float* __restrict__ dx_out,
+                                                     bf16_t* __restrict__ dx_bf, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  float4 dg[NV], db[NV], gm[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[j] = dg[j];
+    const int c = (j * 64 + lane) * 4;
+    gm[j] = c < H ? *reinterpret_cast<const float4*>(gamma + c) : dg[j];
+  }
+  for (int m = wid; m < M; m += nw) {
+    const size_t row = row_map ? (size_t)row_map[m] : (size_t)m;
+    float4 xv[NV], dy[NV];
+    load_row_f32<NV>(x + row * H, H, lane, xv);
+    if (dyb)
+      load_row_bf16<NV>(dyb + (size_t)m * H, H, lane, dy);
+    else
+      load_row_f32<NV>(dyf + (size_t)m * H, H, lane, dy);
+    const float mean = mean_i[m], rstd = rstd_i[m];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < H) {
+        xv[j].x = (xv[j].x - mean) * rstd;
+        xv[j].y = (xv[j].y - mean) * rstd;
+        xv[j].z = (xv[j].z - mean) * rstd;
+        xv[j].w = (xv[j].w - mean) * rstd;
+        dg[j].x += dy[j].x * xv[j].x; dg[j].y += dy[j].y * xv[j].y;
+        dg[j].z += dy[j].z * xv[j].z; dg[j].w += dy[j].w * xv[j].w;
+        db[j].x += dy[j].x; db[j].y += dy[j].y; db[j].z += dy[j].z; db[j].w += dy[j].w;
+        dy[j].x *= gm[j].x; dy[j].y *= gm[j].y; dy[j].z *= gm[j].z; dy[j].w *= gm[j].w;
+        c1 += dy[j].x + dy[j].y + dy[j].z + dy[j].w;
+        c2 += dy[j].x * xv[j].x + dy[j].y * xv[j].y + dy[j].z * xv[j].z + dy[j].w * xv[j].w;
+      }
+    }
+    c1 = wave_sum(c1) / (float)H;
+    c2 = wave_sum(c2) / (float)H;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < H) {
+        float4 d;
+        d.x = rstd * (dy[j].x - c1 - xv[j].x * c2);
+        d.y = rstd * (dy[j].y - c1 - xv[j].y * c2);
+        d.z = rstd * (dy[j].z - c1 - xv[j].z * c2);
+        d.w = rstd * (dy[j].w - c1 - xv[j].w * c2);
+        if (add_to) {
+          const float4 a = *reinterpret_cast<const float4*>(add_to + row * H + c);
+          d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+        }
+        *reinterpret_cast<float4*>(dx_out + row * H + c) = d;
+        if (dx_bf) store_bf16x4(dx_bf + row * H + c, d);
+      }
+    }
+  }
+  if (part) write_partials<NV>(dg, db, H, part, gridDim.x, red);
+}
+
+// ------------------------------------------------------------------------------------ embeddings
+template <int NV>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, int B, int S, int H,
+                                                        const float* __restrict__ wte, const float* __restrict__ wpe,
+                                                        const float* __restrict__ att, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps,
+                                                        float* __restrict__ h0, float* __restrict__ mean_o,
+                                                        float* __restrict__ rstd_o) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= B * S) return;
+  const int b = m / S, s = m % S;
+  float4 v[NV], t[NV];
+  load_row_f32<NV>(wte + (size_t)ids[m] * H, H, lane, v);
+  if (att) {
+    load_row_f32<NV>(att + (size_t)b * H, H, lane, t);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) { v[j].x += t[j].x; v[j].y += t[j].y; v[j].z += t[j].z; v[j].w += t[j].w; }
+  }
+  float mean = 0.f, rstd = 1.f;
+  if (gamma) {
+    row_stats<NV>(v, H, lane, eps, mean, rstd);
+    if (lane == 0) { mean_o[m] = mean; rstd_o[m] = rstd; }
+  }
+  load_row_f32<NV>(wpe + (size_t)s * H, H, lane, t);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < H) {
+      float4 y = v[j];
+      if (gamma) {
+        const float4 g = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 bb = *reinterpret_cast<const float4*>(beta + c);
+        y.x = (y.x - mean) * rstd * g.x + bb.x; y.y = (y.y - mean) * rstd * g.y + bb.y;
+        y.z = (y.z - mean) * rstd * g.z + bb.z; y.w = (y.w - mean) * rstd * g.w + bb.w;
+      }
+      y.x += t[j].x; y.y += t[j].y; y.z += t[j].z; y.w += t[j].w;
+      *reinterpret_cast<float4*>(h0 + (size_t)m * H + c) = y;
+    }
+  }
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 d) {
+  atomicAdd(p + 0, d.x);
+  atomicAdd(p + 1, d.y);
+  atomicAdd(p + 2, d.z);
+  atomicAdd(p + 3, d.w);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, const long long* __restrict__ ids,
+                                                        const int* __restrict__ row_mask, int B, int S, int H,
+                                                        const float* __restrict__ wte, const float* __restrict__ att,
+                                                        const float* __restrict__ gamma, const float* __restrict__ mean_i,
+                                                        const float* __restrict__ rstd_i, float* __restrict__ dwte,
+                                                        float* __restrict__ dwpe, float* __restrict__ datt,
+                                                        float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nw = gridDim.x * 4;
+  float4 dg[NV], db[NV], gm[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    db[j] = dg[j];
+    const int c = (j * 64 + lane) * 4;
+    gm[j] = (gamma && c < H) ? *reinterpret_cast<const float4*>(gamma + c) : dg[j];
+  }
+  const int M = B * S;
+  for (int m = wid; m < M; m += nw) {
+    if (row_mask && row_mask[m] == 0) continue;  // gradient of a padded position is exactly zero
+    const int b = m / S, s = m % S;
+    const long long id = ids[m];
+    float4 dy[NV];
+    load_row_f32<NV>(g + (size_t)m * H, H, lane, dy);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < H) atomic_add4(dwpe + (size_t)s * H + c, dy[j]);
+    }
+    if (gamma) {
+      float4 xv[NV], t[NV];
+      load_row_f32<NV>(wte + (size_t)id * H, H, lane, xv);
+      if (att) {
+        load_row_f32<NV>(att + (size_t)b * H, H, lane, t);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) { xv[j].x += t[j].x; xv[j].y += t[j].y; xv[j].z += t[j].z; xv[j].w += t[j].w; }
+      }
+      const float mean = mean_i[m], rstd = rstd_i[m];
+      float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < H) {
+          xv[j].x = (xv[j].x - mean) * rstd; xv[j].y = (xv[j].y - mean) * rstd;
+          xv[j].z = (xv[j].z - mean) * rstd; xv[j].w = (xv[j].w - mean) * rstd;
+          dg[j].x += dy[j].x * xv[j].x; dg[j].y += dy[j].y * xv[j].y;
+          dg[j].z += dy[j].z * xv[j].z; dg[j].w += dy[j].w * xv[j].w;
+          db[j].x += dy[j].x; db[j].y += dy[j].y; db[j].z += dy[j].z; db[j].w += dy[j].w;
+          dy[j].x *= gm[j].x; dy[j].y *= gm[j].y; dy[j].z *= gm[j].z; dy[j].w *= gm[j].w;
+          c1 += dy[j].x + dy[j].y + dy[j].z + dy[j].w;
+          c2 += dy[j].x * xv[j].x + dy[j].y * xv[j].y + dy[j].z * xv[j].z + dy[j].w * xv[j].w;
+        }
+      }
+      c1 = wave_sum(c1) / (float)H;
+      c2 = wave_sum(c2) / (float)H;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        dy[j].x = rstd * (dy[j].x - c1 - xv[j].x * c2); dy[j].y = rstd * (dy[j].y - c1 - xv[j].y * c2);
+        dy[j].z = rstd * (dy[j].z - c1 - xv[j].z * c2); dy[j].w = rstd * (dy[j].w - c1 - xv[j].w * c2);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < H) {
+        atomic_add4(dwte + (size_t)id * H + c, dy[j]);
+        if (datt) atomic_add4(datt + (size_t)b * H + c, dy[j]);
+      }
+    }
+  }
+  if (part && gamma) write_partials<NV>(dg, db, H, part, gridDim.x, red);
+}
+
+// ------------------------------------------------------------------------------------ column sums
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts, int H, float* __restrict__ out,
+                                     int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float s = 0.f;
+  for (int b = 0; b < nparts; ++b) s += part[(size_t)b * H + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// part[blockIdx.y, n] = sum over this block's rows of x[m, n]; 8 columns per thread.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ xb, const float* __restrict__ xf,
+                                                     int M, int N, int ld, int rows_per_blk, float* __restrict__ part) {
+  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c0 >= N) return;
+  const int r0 = blockIdx.y * rows_per_blk;
+  const int r1 = min(M, r0 + rows_per_blk);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bool full = c0 + 8 <= N;
+  for (int r = r0; r < r1; ++r) {
+    if (xb) {
+      if (full) {
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + (size_t)r * ld + c0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+      } else {
+        for (int i = 0; i < 8 && c0 + i < N; ++i) acc[i] += (float)xb[(size_t)r * ld + c0 + i];
+      }
+    } else {
+      for (int i = 0; i < 8 && c0 + i < N; ++i) acc[i] += xf[(size_t)r * ld + c0 + i];
+    }
+  }
+  for (int i = 0; i < 8 && c0 + i < N; ++i) part[(size_t)blockIdx.y * N + c0 + i] = acc[i];
+}
+
+int nv_for(int H) { return (H + 255) / 256; }
+
+}  // namespace
+
+#define DISPATCH_NV(NVV, CALL)                       \
+  switch (NVV) {                                     \
+    case 1: { constexpr int NV = 1; CALL; } break;   \
+    case 2: { constexpr int NV = 2; CALL; } break;   \
+    case 3: { constexpr int NV = 3; CALL; } break;   \
+    case 4: { constexpr int NV = 4; CALL; } break;   \
+    case 5: { constexpr int NV = 5; CALL; } break;   \
+    case 6: { constexpr int NV = 6; CALL; } break;   \
+    case 7: { constexpr int NV = 7; CALL; } break;   \
+    default: { constexpr int NV = 8; CALL; } break;  \
+  }
+
+static int check_h(const char* who, int H) {
+  if (H <= 0 || (H & 3) || H > MAXV * 256) {
+    set_error("%s: H=%d must be a positive multiple of 4 and <= %d", who, H, MAXV * 256);
+    return PGCA_ERR_INVALID;
+  }
+  return PGCA_OK;
+}
+
+extern "C" int pgca_layernorm_fwd(const float* x, const int32_t* row_map, int32_t M, int32_t H, const float* gamma,
+                                  const float* beta, float eps, void* y_bf16, float* y_f32, float* mean, float* rstd,
+                                  void* stream) {
+  if (check_h("pgca_layernorm_fwd", H)) return PGCA_ERR_INVALID;
+  if (!x || !gamma || !beta || M <= 0 || (!y_bf16 && !y_f32)) {
+    set_error("pgca_layernorm_fwd: bad arguments");
+    return PGCA_ERR_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((M + 3) / 4), block(256);
+  DISPATCH_NV(nv_for(H), hipLaunchKernelGGL((ln_fwd_kernel<NV>), grid, block, 0, s, x, row_map, M, H, gamma, beta,
+                                            eps, (bf16_t*)y_bf16, y_f32, mean, rstd));
+  return check_launch("pgca_layernorm_fwd");
+}
+
+extern "C" int pgca_layernorm_bwd_blocks(int32_t M) {
+  int b = (M + 3) / 4;
+  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
+
+extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
+                                  int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
+                                  const float* add_to, float* dx_out, void* dx_bf16, float* part, void* stream) {
+  if (check_h("pgca_layernorm_bwd", H)) return PGCA_ERR_INVALID;
+  if ((!dy_bf16) == (!dy_f32) || !x || !gamma || !mean || !rstd || !dx_out || M <= 0) {
+    set_error("pgca_layernorm_bwd: bad arguments");
+    return PGCA_ERR_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(pgca_layernorm_bwd_blocks(M)), block(256);
+  const int nv = nv_for(H);
+  const size_t lds = (size_t)2 * 4 * nv * 256 * sizeof(float);
+  DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32, x,
+                                     row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part));
+  return check_launch("pgca_layernorm_bwd");
+}
+
+extern "C" int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, float* out, int32_t accumulate,
+                                  void* stream) {
+  if (!part || !out || nparts <= 0 || H <= 0) {
+    set_error("pgca_colsum_finish: bad arguments");
+    return PGCA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nparts, H,
+                     out, accumulate);
+  return check_launch("pgca_colsum_finish");
+}
+
+extern "C" int pgca_colsum_blocks(int32_t M) {
+  int b = (M + 63) / 64;
+  return b < 1 ? 1 : (b > 256 ? 256 : b);
+}
+
+extern "C" int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, int32_t ld, float* part,
+                           void* stream) {
+  if ((!x_bf16) == (!x_f32) || !part || M <= 0 || N <= 0 || ld < N || (x_bf16 && (ld & 7))) {
+    set_error("pgca_colsum: bad arguments");
+    return PGCA_ERR_INVALID;
+  }
+  const int nb = pgca_colsum_blocks(M);
+  const int rows = (M + nb - 1) / nb;
+  dim3 grid((N + 2047) / 2048, nb), block(256);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x_bf16, x_f32, M, N, ld, rows,
+                     part);
+  return check_launch("pgca_colsum");
+}
+
+extern "C" int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t H, const float* wte, const float* wpe,
+                              const float* attended, const float* gamma, const float* beta, float eps, float* h0,
+                              float* mean, float* rstd, void* stream) {
+  if (check_h("pgca_embed_fwd", H)) return PGCA_ERR_INVALID;
+  if (!ids || !wte || !wpe || !h0 || B <= 0 || S <= 0 || (gamma && (!beta || !mean || !rstd))) {
+    set_error("pgca_embed_fwd: bad arguments");
+    return PGCA_ERR_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((B * S + 3) / 4), block(256);
+  DISPATCH_NV(nv_for(H), hipLaunchKernelGGL((embed_fwd_kernel<NV>), grid, block, 0, s, (const long long*)ids, B, S, H,
+                                            wte, wpe, attended, gamma, beta, eps, h0, mean, rstd));
+  return check_launch("pgca_embed_fwd");
+}
+
+extern "C" int pgca_embed_bwd_blocks(int32_t B, int32_t S) { return pgca_layernorm_bwd_blocks(B * S); }
+
+extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t* row_mask, int32_t B, int32_t S,
+                              int32_t H, const float* wte, const float* attended, const float* gamma,
+                              const float* mean, const float* rstd, float* dwte, float* dwpe, float* dattended,
+                              float* part, void* stream) {
+  if (check_h("pgca_embed_bwd", H)) return PGCA_ERR_INVALID;
+  if (!g || !ids || !dwte || !dwpe || B <= 0 || S <= 0 || (gamma && (!wte || !mean || !rstd || !part))) {
+    set_error("pgca_embed_bwd: bad arguments");
+    return PGCA_ERR_INVALID;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(pgca_embed_bwd_blocks(B, S)), block(256);
+  const int nv = nv_for(H);
+  const size_t lds = (size_t)2 * 4 * nv * 256 * sizeof(float);
+  DISPATCH_NV(nv, hipLaunchKernelGGL((embed_bwd_kernel<NV>), grid, block, lds, s, g, (const long long*)ids, row_mask, B,
+                                     S, H, wte, attended, gamma, mean, rstd, dwte, dwpe, dattended, part));
+  return check_launch("pgca_embed_bwd");
+}

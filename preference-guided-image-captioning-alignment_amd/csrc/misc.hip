@@ -1,0 +1,435 @@
+// Small HBM-bound kernels of the step: ViT patch gather, sequence reduce + DPO loss,
+// masked mean pool, L2 normalise, NT-Xent scalar reduce, fused clip/AdamW over flat buffers.
+#include "common.h"
+
+using namespace pgca;
+
+namespace {
+
+// ------------------------------------------------------------------------------------ ViT input
+// out[(b*G*G + gy*G + gx), c*P*P + ky*P + kx] = pixels[b, c, gy*P+ky, gx*P+kx]   (bf16)
+__global__ void patchify_kernel(const float* __restrict__ px, int B, int I, int P, bf16_t* __restrict__ out) {
+  const int G = I / P, D = 3 * P * P;
+  const size_t total = (size_t)B * G * G * D / 4;  // 4 consecutive kx per thread (P % 4 == 0)
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t e = i * 4;
+    const int col = (int)(e % D);
+    const size_t row = e / D;
+    const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+    const int b = (int)(row / (G * G)), gy = (int)(row / G) % G, gx = (int)(row % G);
+    const float4 v = *reinterpret_cast<const float4*>(px + (((size_t)b * 3 + c) * I + gy * P + ky) * I + gx * P + kx);
+    bf16x4 t;
+    t[0] = (bf16_t)v.x; t[1] = (bf16_t)v.y; t[2] = (bf16_t)v.z; t[3] = (bf16_t)v.w;
+    *reinterpret_cast<bf16x4*>(out + e) = t;
+  }
+}
+
+__global__ void vit_assemble_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
+                                    const float* __restrict__ pos, int B, int T, int H, float* __restrict__ x) {
+  const size_t total = (size_t)B * T * H;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % H);
+    const int tkn = (int)((i / H) % T);
+    const size_t b = i / ((size_t)H * T);
+    const float v = tkn == 0 ? cls[c] : pe[(b * (T - 1) + (tkn - 1)) * H + c];
+    x[i] = v + pos[(size_t)tkn * H + c];
+  }
+}
+
+// ------------------------------------------------------------------------------------ sequence reduce / DPO
+// One wave per sequence: compact rows of a sequence are contiguous [row_begin[q], row_begin[q+1]).
+__global__ void seq_reduce_kernel(const float* __restrict__ tok, const int* __restrict__ seq_of_row, int nrows,
+                                  int nseq, const int* __restrict__ seq_count, int mode, float* __restrict__ out) {
+  const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nseq) return;
+  // rows of sequence q: binary search is overkill - rows are sorted by sequence; scan with stride 64
+  float s = 0.f;
+  for (int r = lane; r < nrows; r += 64)
+    if (seq_of_row[r] == q) s += tok[r];
+  s = wave_sum(s);
+  if (lane == 0) out[q] = mode ? s / (float)seq_count[q] : s;
+}
+
+__global__ void row_scale_kernel(const float* __restrict__ dseq, const int* __restrict__ seq_of_row,
+                                 const int* __restrict__ seq_count, int nrows, int mode, float* __restrict__ rs) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const int q = seq_of_row[r];
+  rs[r] = mode ? dseq[q] / (float)seq_count[q] : dseq[q];
+}
+
+__device__ __forceinline__ float log_sigmoid(float z) {  // stable: min(z,0) - log1p(exp(-|z|))
+  return fminf(z, 0.f) - log1pf(__expf(-fabsf(z)));
+}
+__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + __expf(-z)); }
+
+// single block; B pairs
+__global__ void dpo_loss_kernel(const float* __restrict__ pw, const float* __restrict__ pl,
+                                const float* __restrict__ rw, const float* __restrict__ rl, int B, float beta,
+                                float ls, float* __restrict__ loss, float* __restrict__ dpw, float* __restrict__ dpl,
+                                float* __restrict__ metrics) {
+  __shared__ float red[5][4];
+  float a_loss = 0.f, a_margin = 0.f, a_acc = 0.f, a_w = 0.f, a_l = 0.f;
+  for (int i = threadIdx.x; i < B; i += blockDim.x) {
+    const float pol = pw[i] - pl[i];
+    const float ref = rw ? rw[i] - rl[i] : 0.f;
+    const float z = beta * (pol - ref);
+    // label smoothing (components.py:223-228): BCE with target (1 - ls); ls == 0 -> -logsigmoid(z)
+    const float tgt = 1.f - ls;
+    a_loss += -(tgt * log_sigmoid(z) + (1.f - tgt) * log_sigmoid(-z));
+    const float dz = -(tgt * (1.f - sigmoidf(z)) - (1.f - tgt) * sigmoidf(z)) / (float)B;
+    if (dpw) dpw[i] = beta * dz;
+    if (dpl) dpl[i] = -beta * dz;
+    a_margin += pol - ref;
+    a_acc += pol > ref ? 1.f : 0.f;
+    a_w += pw[i];
+    a_l += pl[i];
+  }
+  float v[5] = {a_loss, a_margin, a_acc, a_w, a_l};
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const float s = wave_sum(v[k]);
+    if (lane == 0) red[k][w] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    const float s = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)B;
+    if (threadIdx.x == 0)
+      loss[0] = s;
+    else if (metrics)
+      metrics[threadIdx.x - 1] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------ pooling / normalise
+__global__ void masked_mean_fwd_kernel(const float* __restrict__ f, const int* __restrict__ mask, int S, int H,
+                                       float* __restrict__ pooled) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  float s = 0.f;
+  int cnt = 0;
+  for (int t = 0; t < S; ++t) {
+    const int m = mask[b * S + t];
+    cnt += m;
+    if (m) s += f[((size_t)b * S + t) * H + c] * (float)m;
+  }
+  pooled[(size_t)b * H + c] = s / (float)(cnt < 1 ? 1 : cnt);
+}
+__global__ void masked_mean_bwd_kernel(const float* __restrict__ dp, const int* __restrict__ mask, int S, int H,
+                                       float* __restrict__ df) {
+  const int b = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  int cnt = 0;
+  for (int t = 0; t < S; ++t) cnt += mask[b * S + t];
+  const float g = dp[(size_t)b * H + c] / (float)(cnt < 1 ? 1 : cnt);
+  for (int t = 0; t < S; ++t) df[((size_t)b * S + t) * H + c] = g * (float)mask[b * S + t];
+}
+
+// one wave per row
+__global__ void l2norm_fwd_kernel(const float* __restrict__ x, int B, int P, float* __restrict__ y,
+                                  float* __restrict__ norm) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= B) return;
+  float s = 0.f;
+  for (int c = lane; c < P; c += 64) { const float v = x[(size_t)r * P + c]; s += v * v; }
+  const float n = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int c = lane; c < P; c += 64) y[(size_t)r * P + c] = x[(size_t)r * P + c] / n;
+  if (lane == 0 && norm) norm[r] = n;
+}
+__global__ void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                  const float* __restrict__ norm, int B, int P, float* __restrict__ dx) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= B) return;
+  float s = 0.f;
+  for (int c = lane; c < P; c += 64) s += dy[(size_t)r * P + c] * y[(size_t)r * P + c];
+  s = wave_sum(s);
+  const float inv = 1.f / norm[r];
+  for (int c = lane; c < P; c += 64) dx[(size_t)r * P + c] = (dy[(size_t)r * P + c] - y[(size_t)r * P + c] * s) * inv;
+}
+
+__global__ void ntxent_loss_kernel(const float* __restrict__ lr, const float* __restrict__ lc,
+                                   const float* __restrict__ diag, int n_local, int n_total, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n_local; i += blockDim.x) s += (lr[i] - diag[i]) + (lc[i] - diag[i]);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (2.f * (float)n_total);
+}
+
+// ------------------------------------------------------------------------------------ optimiser
+constexpr int SQ_BLOCK_ELEMS = 256 * 4 * 16;  // 16 float4 per thread
+
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, long long n, float* __restrict__ part) {
+  __shared__ float red[4];
+  const long long base = (long long)blockIdx.x * SQ_BLOCK_ELEMS;
+  float s = 0.f;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const long long e = base + ((long long)i * 256 + threadIdx.x) * 4;
+    if (e + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + e);
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (long long k = e; k < n && k < e + 4; ++k) s += g[k] * g[k];
+    }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void step_control_kernel(const float* __restrict__ part, int nparts, float max_norm, float base_lr,
+                                    int warmup, int total_steps, int sched_stride, float beta1, float beta2,
+                                    float grad_scale, float* __restrict__ ctrl) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += (double)part[i];
+  // wave reduce in double via two floats is lossy; use shuffles on the 64-bit value
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = (red[0] + red[1] + red[2] + red[3]) * (double)grad_scale * (double)grad_scale;
+    const float norm = (float)sqrt(tot);
+    const bool finite = isfinite(norm);
+    ctrl[0] = norm;
+    ctrl[1] = finite ? 1.f : 0.f;
+    ctrl[2] = (max_norm > 0.f) ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    if (finite) {
+      // lr is read from the schedule BEFORE it advances (optimizer.step() then scheduler.step(),
+      // reference trainer.py:518-519,626-627); the schedule advances `sched_stride` per optimiser
+      // step (= num_processes under Accelerate).
+      const float sched = ctrl[7];
+      float mult;
+      if (sched < (float)warmup) {
+        mult = sched / (float)(warmup < 1 ? 1 : warmup);
+      } else {
+        const float denom = (float)((total_steps - warmup) < 1 ? 1 : (total_steps - warmup));
+        const float prog = (sched - (float)warmup) / denom;
+        mult = fmaxf(0.f, 0.5f * (1.f + cosf(3.14159265358979323846f * prog)));
+      }
+      const float step = ctrl[6] + 1.f;
+      ctrl[3] = base_lr * mult;
+      ctrl[4] = 1.f - powf(beta1, step);
+      ctrl[5] = 1.f - powf(beta2, step);
+      ctrl[6] = step;
+      ctrl[7] = sched + (float)sched_stride;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ pb, long long n, const float* __restrict__ ctrl,
+                                                    float wd, float b1, float b2, float eps, float grad_scale) {
+  if (ctrl[1] == 0.f) return;  // non-finite gradients: skip the step on every rank alike
+  const float gs = ctrl[2] * grad_scale, lr = ctrl[3], bc1 = ctrl[4], bc2s = sqrtf(ctrl[5]);
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += stride) {
+    // flat segments are padded to multiples of 64 elements, so e + 4 <= n always holds
+    float4 pv = *reinterpret_cast<const float4*>(p + e);
+    const float4 gv = *reinterpret_cast<const float4*>(g + e);
+    float4 mv = *reinterpret_cast<const float4*>(m + e);
+    float4 vv = *reinterpret_cast<const float4*>(v + e);
+    float* pp = &pv.x;
+    const float* gp = &gv.x;
+    float* mp = &mv.x;
+    float* vp = &vv.x;
+    bf16x4 ob;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gp[k] * gs;
+      float w = pp[k] * (1.f - lr * wd);
+      mp[k] = b1 * mp[k] + (1.f - b1) * gg;
+      vp[k] = b2 * vp[k] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vp[k]) / bc2s + eps;
+      w -= (lr / bc1) * (mp[k] / denom);
+      pp[k] = w;
+      ob[k] = (bf16_t)w;
+    }
+    *reinterpret_cast<float4*>(p + e) = pv;
+    *reinterpret_cast<float4*>(m + e) = mv;
+    *reinterpret_cast<float4*>(v + e) = vv;
+    if (pb) *reinterpret_cast<bf16x4*>(pb + e) = ob;
+  }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += stride) {
+    if (e + 4 <= n) {
+      const float4 v = *reinterpret_cast<const float4*>(x + e);
+      bf16x4 t;
+      t[0] = (bf16_t)v.x; t[1] = (bf16_t)v.y; t[2] = (bf16_t)v.z; t[3] = (bf16_t)v.w;
+      *reinterpret_cast<bf16x4*>(y + e) = t;
+    } else {
+      for (long long k = e; k < n; ++k) y[k] = (bf16_t)x[k];
+    }
+  }
+}
+
+__global__ void axpy_kernel(const float* __restrict__ x, float alpha, float* __restrict__ y, long long n, int acc) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
+    y[e] = acc ? y[e] + alpha * x[e] : alpha * x[e];
+}
+
+__global__ void gather_rows_bf16_kernel(const bf16_t* __restrict__ src, const int* __restrict__ map, int M, int H,
+                                        bf16_t* __restrict__ dst) {
+  const int chunks = H / 8;
+  const long long total = (long long)M * chunks;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / chunks), c = (int)(i % chunks);
+    *reinterpret_cast<u32x4*>(dst + (size_t)m * H + c * 8) =
+        *reinterpret_cast<const u32x4*>(src + (size_t)map[m] * H + c * 8);
+  }
+}
+
+inline int blocks_for(long long work, int per_block, int cap = 4096) {
+  long long b = (work + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+#define REQUIRE(cond, who)                                 \
+  if (!(cond)) {                                           \
+    set_error(who ": bad arguments (" #cond ")");          \
+    return PGCA_ERR_INVALID;                               \
+  }
+
+extern "C" int pgca_patchify(const float* pixels, int32_t B, int32_t image, int32_t patch, void* out_bf16,
+                             void* stream) {
+  REQUIRE(pixels && out_bf16 && B > 0 && patch > 0 && image % patch == 0 && patch % 4 == 0, "pgca_patchify");
+  const long long work = (long long)B * 3 * image * image / 4;
+  hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, pixels, B, image,
+                     patch, (bf16_t*)out_bf16);
+  return check_launch("pgca_patchify");
+}
+
+extern "C" int pgca_vit_assemble(const float* patch_embeds, const float* cls, const float* pos, int32_t B, int32_t T,
+                                 int32_t H, float* x, void* stream) {
+  REQUIRE(patch_embeds && cls && pos && x && B > 0 && T > 1 && H > 0, "pgca_vit_assemble");
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(blocks_for((long long)B * T * H, 256)), dim3(256), 0,
+                     (hipStream_t)stream, patch_embeds, cls, pos, B, T, H, x);
+  return check_launch("pgca_vit_assemble");
+}
+
+extern "C" int pgca_seq_reduce(const float* tok_lp, const int32_t* seq_of_row, int32_t nrows, int32_t nseq,
+                               const int32_t* seq_count, int32_t mode, float* seq_lp, void* stream) {
+  REQUIRE(tok_lp && seq_of_row && seq_lp && nrows >= 0 && nseq > 0 && (!mode || seq_count), "pgca_seq_reduce");
+  hipLaunchKernelGGL(seq_reduce_kernel, dim3((nseq + 3) / 4), dim3(256), 0, (hipStream_t)stream, tok_lp, seq_of_row,
+                     nrows, nseq, seq_count, mode, seq_lp);
+  return check_launch("pgca_seq_reduce");
+}
+
+extern "C" int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,
+                              int32_t mode, float* row_scale, void* stream) {
+  REQUIRE(dseq && seq_of_row && row_scale && nrows > 0 && (!mode || seq_count), "pgca_row_scale");
+  hipLaunchKernelGGL(row_scale_kernel, dim3((nrows + 255) / 256), dim3(256), 0, (hipStream_t)stream, dseq, seq_of_row,
+                     seq_count, nrows, mode, row_scale);
+  return check_launch("pgca_row_scale");
+}
+
+extern "C" int pgca_dpo_loss(const float* pol_w, const float* pol_l, const float* ref_w, const float* ref_l, int32_t B,
+                             float beta, float label_smoothing, float* loss, float* dpol_w, float* dpol_l,
+                             float* metrics, void* stream) {
+  REQUIRE(pol_w && pol_l && loss && B > 0 && ((!ref_w) == (!ref_l)), "pgca_dpo_loss");
+  hipLaunchKernelGGL(dpo_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pol_w, pol_l, ref_w, ref_l, B, beta,
+                     label_smoothing, loss, dpol_w, dpol_l, metrics);
+  return check_launch("pgca_dpo_loss");
+}
+
+extern "C" int pgca_masked_mean_fwd(const float* feats, const int32_t* mask, int32_t B, int32_t S, int32_t H,
+                                    float* pooled, void* stream) {
+  REQUIRE(feats && mask && pooled && B > 0 && S > 0 && H > 0, "pgca_masked_mean_fwd");
+  hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, feats, mask,
+                     S, H, pooled);
+  return check_launch("pgca_masked_mean_fwd");
+}
+extern "C" int pgca_masked_mean_bwd(const float* dpooled, const int32_t* mask, int32_t B, int32_t S, int32_t H,
+                                    float* dfeats, void* stream) {
+  REQUIRE(dpooled && mask && dfeats && B > 0 && S > 0 && H > 0, "pgca_masked_mean_bwd");
+  hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dpooled, mask,
+                     S, H, dfeats);
+  return check_launch("pgca_masked_mean_bwd");
+}
+
+extern "C" int pgca_l2norm_fwd(const float* x, int32_t B, int32_t P, float* y, float* norm, void* stream) {
+  REQUIRE(x && y && B > 0 && P > 0, "pgca_l2norm_fwd");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, B, P, y, norm);
+  return check_launch("pgca_l2norm_fwd");
+}
+extern "C" int pgca_l2norm_bwd(const float* dy, const float* y, const float* norm, int32_t B, int32_t P, float* dx,
+                               void* stream) {
+  REQUIRE(dy && y && norm && dx && B > 0 && P > 0, "pgca_l2norm_bwd");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, y, norm, B, P, dx);
+  return check_launch("pgca_l2norm_bwd");
+}
+
+extern "C" int pgca_ntxent_loss(const float* lse_r, const float* lse_c, const float* diag, int32_t n_local,
+                                int32_t n_total, float* loss, void* stream) {
+  REQUIRE(lse_r && lse_c && diag && loss && n_local > 0 && n_total >= n_local, "pgca_ntxent_loss");
+  hipLaunchKernelGGL(ntxent_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, lse_r, lse_c, diag, n_local,
+                     n_total, loss);
+  return check_launch("pgca_ntxent_loss");
+}
+
+extern "C" int pgca_sqnorm_blocks(int64_t n) { return (int)((n + SQ_BLOCK_ELEMS - 1) / SQ_BLOCK_ELEMS); }
+
+extern "C" int pgca_sqnorm(const float* g, int64_t n, float* part, void* stream) {
+  REQUIRE(g && part && n > 0 && (((uintptr_t)g & 15) == 0), "pgca_sqnorm");
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(pgca_sqnorm_blocks(n)), dim3(256), 0, (hipStream_t)stream, g, (long long)n,
+                     part);
+  return check_launch("pgca_sqnorm");
+}
+
+extern "C" int pgca_step_control(const float* part, int32_t nparts, float max_norm, float base_lr, int32_t warmup,
+                                 int32_t total_steps, int32_t sched_stride, float beta1, float beta2, float grad_scale,
+                                 float* ctrl, void* stream) {
+  REQUIRE(part && ctrl && nparts > 0, "pgca_step_control");
+  hipLaunchKernelGGL(step_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nparts, max_norm, base_lr,
+                     warmup, total_steps, sched_stride, beta1, beta2, grad_scale, ctrl);
+  return check_launch("pgca_step_control");
+}
+
+extern "C" int pgca_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* ctrl,
+                          float weight_decay, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  REQUIRE(p && g && m && v && ctrl && n > 0 && (n % 4) == 0, "pgca_adamw");
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     (bf16_t*)p_bf16, (long long)n, ctrl, weight_decay, beta1, beta2, eps, grad_scale);
+  return check_launch("pgca_adamw");
+}
+
+extern "C" int pgca_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream) {
+  REQUIRE(x && y_bf16 && n > 0, "pgca_cast_bf16");
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for((n + 3) / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)y_bf16, (long long)n);
+  return check_launch("pgca_cast_bf16");
+}
+
+extern "C" int pgca_axpy(const float* x, float alpha, float* y, int64_t n, int32_t accumulate, void* stream) {
+  REQUIRE(x && y && n > 0, "pgca_axpy");
+  hipLaunchKernelGGL(axpy_kernel, dim3(blocks_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, alpha, y,
+                     (long long)n, accumulate);
+  return check_launch("pgca_axpy");
+}
+
+extern "C" int pgca_gather_rows_bf16(const void* src, const int32_t* row_map, int32_t M, int32_t H, void* dst,
+                                     void* stream) {
+  REQUIRE(src && row_map && dst && M > 0 && H > 0 && (H % 8) == 0, "pgca_gather_rows_bf16");
+  hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(blocks_for((long long)M * H / 8, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)src, row_map, M, H, (bf16_t*)dst);
+  return check_launch("pgca_gather_rows_bf16");
+}

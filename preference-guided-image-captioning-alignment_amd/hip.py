@@ -1,0 +1,279 @@
+"""ctypes binding of ``libpgca_hip.so`` (C ABI: ``include/pgca_hip.h``).
+
+There is NO CPU fallback: if the library is missing or a call fails, a
+``RuntimeError`` is raised.  Wrappers take torch tensors that live on the GPU,
+pass ``data_ptr()`` + sizes and launch on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgca_hip.so")
+
+NT, NN, TN = 0, 1, 2
+EPI_NONE, EPI_GELU_NEW, EPI_QUICK_GELU, EPI_RELU, EPI_TANH = 0, 1, 2, 3, 4
+EPI_DGELU_NEW, EPI_DRELU, EPI_DTANH, EPI_ROWSTATS, EPI_DLOGITS = 5, 6, 7, 8, 9
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("A", _vp), ("B", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32),
+        ("lda", _i32), ("ldb", _i32),
+        ("layout", _i32), ("epilogue", _i32),
+        ("alpha", _f32),
+        ("bias", _vp),
+        ("out_bf16", _vp), ("ld_out_bf16", _i32),
+        ("out_f32", _vp), ("ld_out_f32", _i32),
+        ("accumulate", _i32),
+        ("residual", _vp), ("ld_res", _i32),
+        ("aux_out", _vp), ("aux_in", _vp), ("ld_aux", _i32),
+        ("targets", _vp), ("stat_max", _vp), ("stat_sum", _vp), ("stat_ld", _i32),
+        ("target_val", _vp), ("row_lse", _vp), ("row_scale", _vp),
+        ("out_cols", _i32),
+    ]
+
+
+# name -> argtypes (return type is always int status unless noted)
+_SIGS = {
+    "pgca_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
+    "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
+    "pgca_layernorm_bwd_blocks": [_i32],
+    "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pgca_colsum_finish": [_vp, _i32, _i32, _vp, _i32, _vp],
+    "pgca_colsum_blocks": [_i32],
+    "pgca_colsum": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
+    "pgca_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pgca_embed_fwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp],
+    "pgca_embed_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pgca_embed_bwd_blocks": [_i32, _i32],
+    "pgca_patchify": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_vit_assemble": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_seq_reduce": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
+    "pgca_dpo_loss": [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
+    "pgca_row_scale": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "pgca_masked_mean_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_masked_mean_bwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_l2norm_fwd": [_vp, _i32, _i32, _vp, _vp, _vp],
+    "pgca_l2norm_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "pgca_ntxent_loss": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "pgca_sqnorm_blocks": [_i64],
+    "pgca_sqnorm": [_vp, _i64, _vp, _vp],
+    "pgca_step_control": [_vp, _i32, _f32, _f32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp],
+    "pgca_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _vp],
+    "pgca_cast_bf16": [_vp, _vp, _i64, _vp],
+    "pgca_axpy": [_vp, _f32, _vp, _i64, _i32, _vp],
+    "pgca_gather_rows_bf16": [_vp, _vp, _i32, _i32, _vp, _vp],
+}
+EXPORTS = ["pgca_version", "pgca_last_error"] + list(_SIGS)
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library (after torch, so libamdhip64.so.7 resolves to the loaded runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X path has no fallback. Build it with "
+            "`python -m pgca_amd.build` (hipcc --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    lib.pgca_version.restype = C.c_int
+    lib.pgca_last_error.restype = C.c_char_p
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = sig
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {load().pgca_last_error().decode()}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, *, lda: int = None, ldb: int = None,
+         epilogue: int = EPI_NONE, alpha: float = 1.0, bias: torch.Tensor = None,
+         out_bf16: torch.Tensor = None, ld_out_bf16: int = None, out_f32: torch.Tensor = None, ld_out_f32: int = None,
+         accumulate: bool = False, residual: torch.Tensor = None, ld_res: int = None,
+         aux_out: torch.Tensor = None, aux_in: torch.Tensor = None, ld_aux: int = None,
+         targets: torch.Tensor = None, stat_max: torch.Tensor = None, stat_sum: torch.Tensor = None, stat_ld: int = 0,
+         target_val: torch.Tensor = None, row_lse: torch.Tensor = None, row_scale: torch.Tensor = None,
+         out_cols: int = 0) -> None:
+    a = GemmArgs()
+    a.A, a.B = A.data_ptr(), B.data_ptr()
+    a.M, a.N, a.K = M, N, K
+    a.lda = lda if lda is not None else (K if layout != TN else M)
+    a.ldb = ldb if ldb is not None else (K if layout == NT else N)
+    a.layout, a.epilogue, a.alpha = layout, epilogue, alpha
+    a.bias = _p(bias)
+    a.out_bf16, a.ld_out_bf16 = _p(out_bf16), (ld_out_bf16 if ld_out_bf16 is not None else N)
+    a.out_f32, a.ld_out_f32 = _p(out_f32), (ld_out_f32 if ld_out_f32 is not None else N)
+    a.accumulate = 1 if accumulate else 0
+    a.residual, a.ld_res = _p(residual), (ld_res if ld_res is not None else N)
+    a.aux_out, a.aux_in, a.ld_aux = _p(aux_out), _p(aux_in), (ld_aux if ld_aux is not None else N)
+    a.targets, a.stat_max, a.stat_sum, a.stat_ld = _p(targets), _p(stat_max), _p(stat_sum), stat_ld
+    a.target_val, a.row_lse, a.row_scale = _p(target_val), _p(row_lse), _p(row_scale)
+    a.out_cols = out_cols
+    _check(load().pgca_gemm_bf16(C.byref(a), _stream()), "pgca_gemm_bf16")
+
+
+def rowstats_combine(stat_max, stat_sum, stat_ld, nparts, target_val, M, lse=None, out_logprob=None):
+    _check(load().pgca_rowstats_combine(_p(stat_max), _p(stat_sum), stat_ld, nparts, _p(target_val), M, _p(lse),
+                                        _p(out_logprob), _stream()), "pgca_rowstats_combine")
+
+
+# --------------------------------------------------------------------------- LayerNorm / column sums
+def layernorm_fwd(x, M, H, gamma, beta, eps=1e-5, row_map=None, y_bf16=None, y_f32=None, mean=None, rstd=None):
+    _check(load().pgca_layernorm_fwd(_p(x), _p(row_map), M, H, _p(gamma), _p(beta), eps, _p(y_bf16), _p(y_f32),
+                                     _p(mean), _p(rstd), _stream()), "pgca_layernorm_fwd")
+
+
+def layernorm_bwd_blocks(M: int) -> int:
+    return load().pgca_layernorm_bwd_blocks(M)
+
+
+def layernorm_bwd(x, M, H, gamma, mean, rstd, dx_out, *, dy_bf16=None, dy_f32=None, row_map=None, add_to=None,
+                  dx_bf16=None, part=None):
+    _check(load().pgca_layernorm_bwd(_p(dy_bf16), _p(dy_f32), _p(x), _p(row_map), M, H, _p(gamma), _p(mean),
+                                     _p(rstd), _p(add_to), _p(dx_out), _p(dx_bf16), _p(part), _stream()),
+           "pgca_layernorm_bwd")
+
+
+def colsum_finish(part, nparts, H, out, accumulate=False):
+    _check(load().pgca_colsum_finish(_p(part), nparts, H, _p(out), 1 if accumulate else 0, _stream()),
+           "pgca_colsum_finish")
+
+
+def colsum_blocks(M: int) -> int:
+    return load().pgca_colsum_blocks(M)
+
+
+def colsum(M, N, ld, part, x_bf16=None, x_f32=None):
+    _check(load().pgca_colsum(_p(x_bf16), _p(x_f32), M, N, ld, _p(part), _stream()), "pgca_colsum")
+
+
+# --------------------------------------------------------------------------- attention
+def attention_fwd(qkv, key_mask, B, S, heads, causal, out, lse=None):
+    _check(load().pgca_attention_fwd(_p(qkv), _p(key_mask), B, S, heads, 1 if causal else 0, _p(out), _p(lse),
+                                     _stream()), "pgca_attention_fwd")
+
+
+def attention_bwd(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv):
+    _check(load().pgca_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(key_mask), B, S, heads,
+                                     1 if causal else 0, _p(dqkv), _stream()), "pgca_attention_bwd")
+
+
+# --------------------------------------------------------------------------- embeddings / ViT input
+def embed_fwd(ids, B, S, H, wte, wpe, h0, attended=None, gamma=None, beta=None, eps=1e-5, mean=None, rstd=None):
+    _check(load().pgca_embed_fwd(_p(ids), B, S, H, _p(wte), _p(wpe), _p(attended), _p(gamma), _p(beta), eps, _p(h0),
+                                 _p(mean), _p(rstd), _stream()), "pgca_embed_fwd")
+
+
+def embed_bwd_blocks(B: int, S: int) -> int:
+    return load().pgca_embed_bwd_blocks(B, S)
+
+
+def embed_bwd(g, ids, row_mask, B, S, H, dwte, dwpe, wte=None, attended=None, gamma=None, mean=None, rstd=None,
+              dattended=None, part=None):
+    _check(load().pgca_embed_bwd(_p(g), _p(ids), _p(row_mask), B, S, H, _p(wte), _p(attended), _p(gamma), _p(mean),
+                                 _p(rstd), _p(dwte), _p(dwpe), _p(dattended), _p(part), _stream()), "pgca_embed_bwd")
+
+
+def patchify(pixels, B, image, patch, out_bf16):
+    _check(load().pgca_patchify(_p(pixels), B, image, patch, _p(out_bf16), _stream()), "pgca_patchify")
+
+
+def vit_assemble(patch_embeds, cls, pos, B, T, H, x):
+    _check(load().pgca_vit_assemble(_p(patch_embeds), _p(cls), _p(pos), B, T, H, _p(x), _stream()),
+           "pgca_vit_assemble")
+
+
+# --------------------------------------------------------------------------- sequence reduce / losses
+def seq_reduce(tok_lp, seq_of_row, nrows, nseq, seq_count, mode, seq_lp):
+    _check(load().pgca_seq_reduce(_p(tok_lp), _p(seq_of_row), nrows, nseq, _p(seq_count), mode, _p(seq_lp),
+                                  _stream()), "pgca_seq_reduce")
+
+
+def dpo_loss(pol_w, pol_l, ref_w, ref_l, B, beta, label_smoothing, loss, dpol_w=None, dpol_l=None, metrics=None):
+    _check(load().pgca_dpo_loss(_p(pol_w), _p(pol_l), _p(ref_w), _p(ref_l), B, beta, label_smoothing, _p(loss),
+                                _p(dpol_w), _p(dpol_l), _p(metrics), _stream()), "pgca_dpo_loss")
+
+
+def row_scale(dseq, seq_of_row, seq_count, nrows, mode, out):
+    _check(load().pgca_row_scale(_p(dseq), _p(seq_of_row), _p(seq_count), nrows, mode, _p(out), _stream()),
+           "pgca_row_scale")
+
+
+def masked_mean_fwd(feats, mask, B, S, H, pooled):
+    _check(load().pgca_masked_mean_fwd(_p(feats), _p(mask), B, S, H, _p(pooled), _stream()), "pgca_masked_mean_fwd")
+
+
+def masked_mean_bwd(dpooled, mask, B, S, H, dfeats):
+    _check(load().pgca_masked_mean_bwd(_p(dpooled), _p(mask), B, S, H, _p(dfeats), _stream()),
+           "pgca_masked_mean_bwd")
+
+
+def l2norm_fwd(x, B, P, y, norm=None):
+    _check(load().pgca_l2norm_fwd(_p(x), B, P, _p(y), _p(norm), _stream()), "pgca_l2norm_fwd")
+
+
+def l2norm_bwd(dy, y, norm, B, P, dx):
+    _check(load().pgca_l2norm_bwd(_p(dy), _p(y), _p(norm), B, P, _p(dx), _stream()), "pgca_l2norm_bwd")
+
+
+def ntxent_loss(lse_r, lse_c, diag, n_local, n_total, loss):
+    _check(load().pgca_ntxent_loss(_p(lse_r), _p(lse_c), _p(diag), n_local, n_total, _p(loss), _stream()),
+           "pgca_ntxent_loss")
+
+
+# --------------------------------------------------------------------------- optimiser
+def sqnorm_blocks(n: int) -> int:
+    return load().pgca_sqnorm_blocks(n)
+
+
+def sqnorm(g, n, part):
+    _check(load().pgca_sqnorm(_p(g), n, _p(part), _stream()), "pgca_sqnorm")
+
+
+def step_control(part, nparts, max_norm, base_lr, warmup, total_steps, sched_stride, beta1, beta2, grad_scale, ctrl):
+    _check(load().pgca_step_control(_p(part), nparts, max_norm, base_lr, warmup, total_steps, sched_stride, beta1,
+                                    beta2, grad_scale, _p(ctrl), _stream()), "pgca_step_control")
+
+
+def adamw(p, g, m, v, p_bf16, n, ctrl, weight_decay, beta1, beta2, eps, grad_scale=1.0):
+    _check(load().pgca_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(ctrl), weight_decay, beta1, beta2, eps,
+                             grad_scale, _stream()), "pgca_adamw")
+
+
+def cast_bf16(x, y, n):
+    _check(load().pgca_cast_bf16(_p(x), _p(y), n, _stream()), "pgca_cast_bf16")
+
+
+def axpy(x, alpha, y, n, accumulate=False):
+    _check(load().pgca_axpy(_p(x), alpha, _p(y), n, 1 if accumulate else 0, _stream()), "pgca_axpy")
+
+
+def gather_rows_bf16(src, row_map, M, H, dst):
+    _check(load().pgca_gather_rows_bf16(_p(src), _p(row_map), M, H, _p(dst), _stream()), "pgca_gather_rows_bf16")

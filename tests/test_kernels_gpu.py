@@ -1,0 +1,417 @@
+"""HIP kernels (through the C ABI) against plain fp32 PyTorch / the oracle restatement.
+
+Tolerances: bf16 operands are exact in fp32, accumulation is fp32 in MFMA, so f32 outputs
+are compared at 2e-4 relative to the output scale; bf16 outputs at one bf16 ulp (2^-8
+relative).  Index work (targets, row maps) is bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from pgca_amd import hip as H
+    H.load()
+    return H
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+def close(a, b, rel, what=""):
+    a, b = a.float(), b.float()
+    scale = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max())
+    assert err <= rel * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.3e} > {rel})"
+
+
+def operands(layout, M, N, K, seed):
+    a = rnd(M, K, seed=seed).bfloat16()
+    b = rnd(K, N, seed=seed + 1).bfloat16()  # math: C = a @ b
+    A = a.contiguous() if layout != 2 else a.t().contiguous()          # TN: stored [K, M]
+    B = b.t().contiguous() if layout == 0 else b.contiguous()          # NT: stored [N, K]
+    return a, b, A, B
+
+
+SHAPES = [(128, 128, 64), (256, 384, 1024), (200, 136, 72), (77, 1000, 128), (1, 8, 8), (130, 264, 200)]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("shape", SHAPES)
+def test_gemm_layouts_and_edges(hip, layout, shape):
+    M, N, K = shape
+    if layout == 2 and M % 8:   # TN: A is [K, M], row stride must be a multiple of 8 elements
+        ldm = (M + 7) // 8 * 8
+    else:
+        ldm = M
+    a, b, A, B = operands(layout, M, N, K, seed=layout * 100 + M)
+    ldb = None
+    if layout == 2 and ldm != M:
+        A = torch.zeros(K, ldm, dtype=torch.bfloat16, device=dev())
+        A[:, :M] = a.t()
+    if layout != 0 and N % 8:
+        ldn = (N + 7) // 8 * 8
+        Bp = torch.zeros(K, ldn, dtype=torch.bfloat16, device=dev())
+        Bp[:, :N] = b
+        B, ldb = Bp, ldn
+    if layout != 2 and K % 8:
+        pytest.skip("K-contiguous operands need K % 8 == 0")
+    bias = rnd(N, seed=5)
+    out_f = torch.full((M, N), float("nan"), device=dev())
+    out_b = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    hip.gemm(A, B, M, N, K, layout, lda=(ldm if layout == 2 else None), ldb=ldb, bias=bias, out_f32=out_f,
+             out_bf16=out_b)
+    ref = a.float() @ b.float() + bias
+    close(out_f, ref, 2e-4, "f32 out")
+    close(out_b, ref, 1.0 / 128, "bf16 out")
+
+
+def test_gemm_asymmetric_identity(hip):
+    """A = I with asymmetric B catches a swapped row/col map in the C write."""
+    n = 128
+    eye = torch.eye(n, device=dev()).bfloat16()
+    b = (torch.arange(n * n, device=dev()).float().view(n, n) % 251 - 125).bfloat16()
+    for layout in (0, 1, 2):
+        out = torch.zeros(n, n, device=dev())
+        B = b.t().contiguous() if layout == 0 else b
+        hip.gemm(eye, B, n, n, n, layout, out_f32=out)
+        assert torch.equal(out, b.float()), f"layout {layout}"
+
+
+@pytest.mark.parametrize("epi", ["gelu", "quick_gelu", "relu", "tanh"])
+def test_gemm_activation_epilogues(hip, epi):
+    M, N, K = 192, 320, 256
+    a, b, A, B = operands(1, M, N, K, seed=3)
+    bias = rnd(N, seed=9)
+    pre = a.float() @ b.float() + bias
+    code = {"gelu": hip.EPI_GELU_NEW, "quick_gelu": hip.EPI_QUICK_GELU, "relu": hip.EPI_RELU, "tanh": hip.EPI_TANH}[epi]
+    ref = {"gelu": R.gelu_new, "quick_gelu": R.quick_gelu, "relu": torch.relu, "tanh": torch.tanh}[epi](pre)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    aux = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    hip.gemm(A, B, M, N, K, 1, epilogue=code, bias=bias, out_bf16=out, aux_out=aux if "gelu" in epi else None)
+    close(out, ref, 1.0 / 100, epi)
+    if "gelu" in epi:
+        close(aux, pre, 1.0 / 128, "pre-activation")
+
+
+def test_gemm_derivative_epilogues_residual_accumulate(hip):
+    M, N, K = 160, 256, 128
+    a, b, A, B = operands(0, M, N, K, seed=21)
+    acc = a.float() @ b.float()
+    pre = rnd(M, N, seed=4).bfloat16()
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    hip.gemm(A, B, M, N, K, 0, epilogue=hip.EPI_DGELU_NEW, aux_in=pre, out_bf16=out)
+    x = pre.float().requires_grad_()
+    R.gelu_new(x).backward(acc)
+    close(out, x.grad, 1.0 / 100, "dgelu")
+    act = torch.relu(pre)
+    hip.gemm(A, B, M, N, K, 0, epilogue=hip.EPI_DRELU, aux_in=act, out_bf16=out)
+    close(out, acc * (act.float() > 0), 1.0 / 128, "drelu")
+    th = torch.tanh(pre.float()).bfloat16()
+    hip.gemm(A, B, M, N, K, 0, epilogue=hip.EPI_DTANH, aux_in=th, out_bf16=out)
+    close(out, acc * (1 - th.float() ** 2), 1.0 / 128, "dtanh")
+    # residual add (in place on the f32 stream) and gradient accumulation
+    res = rnd(M, N, seed=6)
+    stream = res.clone()
+    hip.gemm(A, B, M, N, K, 0, residual=stream, out_f32=stream)
+    close(stream, acc + res, 2e-4, "residual in place")
+    hip.gemm(A, B, M, N, K, 0, out_f32=stream, accumulate=True, alpha=0.5)
+    close(stream, 1.5 * acc + res, 2e-4, "accumulate")
+
+
+def test_lm_head_rowstats_and_dlogits(hip):
+    """Fused LM head: log-prob gather without logits in HBM (model.py:1069-1079), and the
+    recomputed dlogits = g * (softmax - onehot)."""
+    M, V, K = 150, 1004, 128          # V not a multiple of 8 or of the 128 tile
+    Vp = (V + 127) // 128 * 128
+    h = rnd(M, K, seed=1, scale=0.5).bfloat16()
+    wte = torch.zeros(Vp, K, dtype=torch.bfloat16, device=dev())
+    wte[:V] = rnd(V, K, seed=2, scale=0.5).bfloat16()
+    tgt = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(3)).to(dev())
+    tgt[0], tgt[1] = 0, V - 1
+    nparts = 2 * (Vp // 128)
+    smax = torch.zeros(M, nparts, device=dev())
+    ssum = torch.zeros(M, nparts, device=dev())
+    tval = torch.zeros(M, device=dev())
+    hip.gemm(h, wte, M, V, K, 0, epilogue=hip.EPI_ROWSTATS, targets=tgt, stat_max=smax, stat_sum=ssum,
+             stat_ld=nparts, target_val=tval)
+    lse = torch.zeros(M, device=dev())
+    lp = torch.zeros(M, device=dev())
+    hip.rowstats_combine(smax, ssum, nparts, 2 * ((V + 127) // 128), tval, M, lse=lse, out_logprob=lp)
+    logits = h.float() @ wte[:V].float().t()
+    ref_lp = torch.log_softmax(logits, -1).gather(-1, tgt[:, None]).squeeze(-1)
+    assert float((lp - ref_lp).abs().max()) <= 2e-4
+    assert float((lse - torch.logsumexp(logits, -1)).abs().max()) <= 2e-4
+    g = rnd(M, seed=8)
+    dl = torch.full((M, Vp), 7.0, dtype=torch.bfloat16, device=dev())
+    hip.gemm(h, wte, M, V, K, 0, epilogue=hip.EPI_DLOGITS, targets=tgt, row_lse=lse, row_scale=g, out_bf16=dl,
+             ld_out_bf16=Vp, out_cols=Vp)
+    ref = g[:, None] * (torch.softmax(logits, -1) - torch.nn.functional.one_hot(tgt, V).float())
+    close(dl[:, :V], ref, 1.0 / 100, "dlogits")
+    assert float(dl[:, V:].abs().max()) == 0.0  # padding columns are written as zeros
+
+
+@pytest.mark.parametrize("H", [64, 512, 768, 1024, 1280, 1600])
+def test_layernorm_fwd_bwd(hip, H):
+    M = 37
+    x = rnd(M + 5, H, seed=H)
+    gamma, beta = rnd(H, seed=1) * 0.1 + 1, rnd(H, seed=2) * 0.1
+    rmap = torch.randperm(M + 5, generator=torch.Generator().manual_seed(0))[:M].int().to(dev())
+    yb = torch.zeros(M, H, dtype=torch.bfloat16, device=dev())
+    yf = torch.zeros(M, H, device=dev())
+    mean, rstd = torch.zeros(M, device=dev()), torch.zeros(M, device=dev())
+    hip.layernorm_fwd(x, M, H, gamma, beta, row_map=rmap, y_bf16=yb, y_f32=yf, mean=mean, rstd=rstd)
+    xs = x[rmap.long()].clone().requires_grad_()
+    gp, bp = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xs, (H,), gp, bp, 1e-5)
+    close(yf, ref, 1e-5, "ln fwd")
+    close(yb, ref, 1.0 / 128, "ln fwd bf16")
+    dy = rnd(M, H, seed=3)
+    ref.backward(dy)
+    add = rnd(M + 5, H, seed=4)
+    dx = torch.zeros(M + 5, H, device=dev())
+    nb = hip.layernorm_bwd_blocks(M)
+    part = torch.zeros(2, nb, H, device=dev())
+    hip.layernorm_bwd(x, M, H, gamma, mean, rstd, dx, dy_f32=dy, row_map=rmap, add_to=add, part=part)
+    close(dx[rmap.long()] - add[rmap.long()], xs.grad, 2e-5, "ln dx")
+    dg, db = torch.zeros(H, device=dev()), torch.ones(H, device=dev())
+    hip.colsum_finish(part[0], nb, H, dg)
+    hip.colsum_finish(part[1], nb, H, db, accumulate=True)
+    close(dg, gp.grad, 2e-5, "dgamma")
+    close(db - 1, bp.grad, 2e-5, "dbeta")
+    # bf16 dy path + bf16 copy of dx
+    dxb = torch.zeros(M + 5, H, dtype=torch.bfloat16, device=dev())
+    hip.layernorm_bwd(x, M, H, gamma, mean, rstd, dx, dy_bf16=dy.bfloat16(), row_map=rmap, dx_bf16=dxb)
+    close(dxb[rmap.long()], xs.grad, 1.0 / 50, "ln dx (bf16 dy)")
+
+
+def test_colsum(hip):
+    M, N = 300, 1000
+    x = rnd(M, N, seed=1)
+    nb = hip.colsum_blocks(M)
+    part = torch.zeros(nb, N, device=dev())
+    hip.colsum(M, N, N, part, x_bf16=x.bfloat16())
+    out = torch.zeros(N, device=dev())
+    hip.colsum_finish(part, nb, N, out)
+    close(out, x.bfloat16().float().sum(0), 1e-5, "colsum bf16")
+    hip.colsum(M, N, N, part, x_f32=x)
+    hip.colsum_finish(part, nb, N, out)
+    close(out, x.sum(0), 1e-5, "colsum f32")
+
+
+def attn_ref(qkv, mask, B, S, heads, causal):
+    H = heads * 64
+    q, k, v = qkv.float().view(B, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    allowed = torch.ones(S, S, dtype=torch.bool, device=qkv.device)
+    if causal:
+        allowed = torch.tril(allowed)
+    allowed = allowed[None, None] & (mask[:, None, None, :] != 0)
+    s = s.masked_fill(~allowed, float("-inf"))
+    p = torch.softmax(s, -1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * S, H), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("cfg", [(3, 128, 2, True), (2, 50, 3, False), (4, 37, 1, True), (2, 16, 2, True)])
+def test_attention_fwd_bwd(hip, cfg):
+    B, S, heads, causal = cfg
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, seed=S).bfloat16()
+    lens = torch.tensor([S, max(1, S // 2), max(1, S - 3), 1][:B])
+    mask = (torch.arange(S)[None] < lens[:, None]).int().to(dev())
+    if not causal:
+        mask = torch.ones_like(mask)
+    out = torch.zeros(B * S, H, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(B, heads, S, device=dev())
+    hip.attention_fwd(qkv, mask, B, S, heads, causal, out, lse)
+    x = qkv.float().requires_grad_()
+    ref, ref_lse = attn_ref(x, mask, B, S, heads, causal)
+    close(out, ref, 1.0 / 64, "attn out")
+    assert float((lse - ref_lse).abs().max()) <= 2e-3
+    # backward only where the loss can reach: rows of valid queries
+    valid = (mask.view(B * S, 1) != 0).float()
+    dout = (rnd(B * S, H, seed=7) * valid).bfloat16()
+    ref.backward(dout.float())
+    dqkv = torch.zeros(B * S, 3 * H, dtype=torch.bfloat16, device=dev())
+    hip.attention_bwd(qkv, out, dout, lse, mask, B, S, heads, causal, dqkv)
+    close(dqkv, x.grad, 1.0 / 40, "attn dqkv")
+    # padded keys receive exactly zero gradient
+    pad_rows = (mask.view(-1) == 0)
+    if bool(pad_rows.any()):
+        assert float(dqkv[pad_rows][:, H:].abs().max()) == 0.0
+
+
+def test_embed_fwd_bwd(hip):
+    B, S, H, V = 3, 9, 128, 50
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(0)).to(dev())
+    ids[0, :3] = 7  # repeated ids -> atomics collide
+    wte, wpe = rnd(V, H, seed=1), rnd(16, H, seed=2)
+    att = rnd(B, H, seed=3)
+    gamma, beta = rnd(H, seed=4) * 0.1 + 1, rnd(H, seed=5) * 0.1
+    h0 = torch.zeros(B * S, H, device=dev())
+    mean, rstd = torch.zeros(B * S, device=dev()), torch.zeros(B * S, device=dev())
+    hip.embed_fwd(ids, B, S, H, wte, wpe, h0, attended=att, gamma=gamma, beta=beta, mean=mean, rstd=rstd)
+    wr, pr, ar = wte.clone().requires_grad_(), wpe.clone().requires_grad_(), att.clone().requires_grad_()
+    gr, br = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    ref = torch.nn.functional.layer_norm(wr[ids] + ar[:, None, :], (H,), gr, br, 1e-5) + pr[:S][None]
+    close(h0, ref.view(B * S, H), 1e-5, "embed fwd")
+    rmask = torch.ones(B, S, dtype=torch.int32, device=dev())
+    rmask[1, 5:] = 0
+    g = rnd(B * S, H, seed=6) * rmask.view(-1, 1)
+    ref.view(B * S, H).backward(g)
+    dwte, dwpe, datt = torch.zeros_like(wte), torch.zeros_like(wpe), torch.zeros_like(att)
+    nb = hip.embed_bwd_blocks(B, S)
+    part = torch.zeros(2, nb, H, device=dev())
+    hip.embed_bwd(g, ids, rmask, B, S, H, dwte, dwpe, wte=wte, attended=att, gamma=gamma, mean=mean, rstd=rstd,
+                  dattended=datt, part=part)
+    close(dwte, wr.grad, 2e-5, "dwte")
+    close(dwpe, pr.grad, 2e-5, "dwpe")
+    close(datt, ar.grad, 2e-5, "dattended")
+    dg = torch.zeros(H, device=dev())
+    hip.colsum_finish(part[0], nb, H, dg)
+    close(dg, gr.grad, 2e-5, "embed dgamma")
+    # text-tower form: no cross-attention, no LN
+    hip.embed_fwd(ids, B, S, H, wte, wpe, h0)
+    close(h0, (wte[ids] + wpe[:S][None]).view(B * S, H), 1e-6, "embed fwd (text)")
+    dwte.zero_(); dwpe.zero_()
+    hip.embed_bwd(g, ids, rmask, B, S, H, dwte, dwpe)
+    ref_dwte = torch.zeros_like(wte).index_add_(0, ids.view(-1), g)
+    close(dwte, ref_dwte, 1e-5, "dwte (text)")
+
+
+def test_patchify_and_assemble(hip):
+    B, I, P, Hd = 2, 64, 32, 128
+    px = rnd(B, 3, I, I, seed=1)
+    G = I // P
+    out = torch.zeros(B * G * G, 3 * P * P, dtype=torch.bfloat16, device=dev())
+    hip.patchify(px, B, I, P, out)
+    ref = px.reshape(B, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, 3 * P * P)
+    assert torch.equal(out, ref.bfloat16())
+    pe, cls, pos = rnd(B * G * G, Hd, seed=2), rnd(Hd, seed=3), rnd(G * G + 1, Hd, seed=4)
+    x = torch.zeros(B, G * G + 1, Hd, device=dev())
+    hip.vit_assemble(pe, cls, pos, B, G * G + 1, Hd, x)
+    ref = torch.cat([cls.expand(B, 1, Hd), pe.view(B, G * G, Hd)], 1) + pos[None]
+    assert torch.equal(x, ref)
+
+
+def test_seq_reduce_dpo_and_row_scale(hip, golden):
+    g = golden("logprob_dpo")
+    B = 8
+    pc, pr, rc, rr = (torch.from_numpy(g[k]).to(dev()) for k in ("dpo_pc", "dpo_pr", "dpo_rc", "dpo_rr"))
+    for name, ls, use_ref in (("std", 0.0, True), ("ls", 0.1, True), ("rf", 0.0, False)):
+        loss = torch.zeros(1, device=dev())
+        dw, dl, met = torch.zeros(B, device=dev()), torch.zeros(B, device=dev()), torch.zeros(4, device=dev())
+        hip.dpo_loss(pc, pr, rc if use_ref else None, rr if use_ref else None, B, 0.1, ls, loss, dw, dl, met)
+        assert abs(float(loss) - float(g[f"dpo_{name}_loss"])) <= 1e-5
+        np.testing.assert_allclose(dw.cpu().numpy(), g[f"dpo_{name}_dpc"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(dl.cpu().numpy(), g[f"dpo_{name}_dpr"], rtol=1e-4, atol=1e-7)
+    # compact-row reduce: rows sorted by sequence
+    counts = torch.tensor([5, 0, 3, 7], dtype=torch.int32)
+    seq_of_row = torch.repeat_interleave(torch.arange(4), counts.long()).int().to(dev())
+    tok = rnd(int(counts.sum()), seed=1)
+    for mode in (0, 1):
+        out = torch.zeros(4, device=dev())
+        hip.seq_reduce(tok, seq_of_row, tok.numel(), 4, counts.to(dev()), mode, out)
+        ref = torch.zeros(4, device=dev()).index_add_(0, seq_of_row.long(), tok)
+        if mode:
+            ref = ref / counts.to(dev())
+        assert torch.allclose(out, ref, atol=1e-5, equal_nan=True)  # empty sequence: 0/0 = NaN like the reference
+    dseq = rnd(4, seed=2)
+    rs = torch.zeros(tok.numel(), device=dev())
+    hip.row_scale(dseq, seq_of_row, counts.to(dev()), tok.numel(), 1, rs)
+    assert torch.allclose(rs, (dseq / counts.to(dev()))[seq_of_row.long()], atol=1e-7)
+
+
+def test_pool_and_normalise(hip):
+    B, S, H = 3, 11, 96
+    f = rnd(B, S, H, seed=1)
+    mask = torch.tensor([[1] * 11, [1] * 4 + [0] * 7, [0] * 11], dtype=torch.int32, device=dev())
+    pooled = torch.zeros(B, H, device=dev())
+    hip.masked_mean_fwd(f, mask, B, S, H, pooled)
+    ref = (f * mask[..., None]).sum(1) / mask.sum(1, keepdim=True).clamp(min=1)
+    close(pooled, ref, 1e-6, "masked mean")
+    dp = rnd(B, H, seed=2)
+    df = torch.zeros(B, S, H, device=dev())
+    hip.masked_mean_bwd(dp, mask, B, S, H, df)
+    close(df, (dp / mask.sum(1, keepdim=True).clamp(min=1))[:, None, :] * mask[..., None], 1e-6, "masked mean bwd")
+    x = rnd(B, 64, seed=3).requires_grad_()
+    y, n = torch.zeros(B, 64, device=dev()), torch.zeros(B, device=dev())
+    hip.l2norm_fwd(x.detach(), B, 64, y, n)
+    ref = torch.nn.functional.normalize(x, p=2, dim=-1)
+    close(y, ref, 1e-6, "l2norm")
+    dy = rnd(B, 64, seed=4)
+    ref.backward(dy)
+    dx = torch.zeros(B, 64, device=dev())
+    hip.l2norm_bwd(dy, y, n, B, 64, dx)
+    close(dx, x.grad, 1e-5, "l2norm bwd")
+
+
+def test_clip_adamw_schedule_matches_reference_optimizer(hip, golden):
+    """sqnorm -> step_control -> adamw reproduces torch AdamW + clip_grad_norm_ + cosine warm-up
+    (fixture from the reference's optimiser wiring, trainer.py:275-289,511-520)."""
+    g = golden("optimizer")
+    sizes = [33 * 17, 129]
+    offs = [0, 576]           # 64-element aligned segments like ParamStore
+    n = 576 + 192
+    p = torch.zeros(n, device=dev())
+    p[:561] = torch.from_numpy(g["p0_init"]).view(-1).to(dev())
+    p[576:576 + 129] = torch.from_numpy(g["p1_init"]).to(dev())
+    m, v, pb = torch.zeros(n, device=dev()), torch.zeros(n, device=dev()), torch.zeros(n, dtype=torch.bfloat16, device=dev())
+    ctrl = torch.zeros(8, device=dev())
+    part = torch.zeros(hip.sqnorm_blocks(n), device=dev())
+    for step in range(4):
+        gr = torch.zeros(n, device=dev())
+        gr[:561] = torch.from_numpy(g[f"g0_{step}"]).view(-1).to(dev())
+        gr[576:705] = torch.from_numpy(g[f"g1_{step}"]).to(dev())
+        hip.sqnorm(gr, n, part)
+        hip.step_control(part, part.numel(), 1.0, 5e-5, 2, 10, 1, 0.9, 0.999, 1.0, ctrl)
+        hip.adamw(p, gr, m, v, pb, n, ctrl, 0.01, 0.9, 0.999, 1e-8)
+        c = ctrl.cpu()
+        assert abs(float(c[0]) - float(g[f"norm_{step}"])) <= 1e-4 * float(g[f"norm_{step}"])
+        assert abs(float(c[3]) - float(g[f"lr_{step}"])) <= 1e-9
+        np.testing.assert_allclose(p[:561].cpu().numpy(), g[f"p0_{step}"].reshape(-1), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(p[576:705].cpu().numpy(), g[f"p1_{step}"], rtol=0, atol=1e-6)
+        assert torch.equal(pb, p.bfloat16())
+    # non-finite gradient: the step is skipped, counters do not advance
+    before, cb = p.clone(), ctrl.clone()
+    gr[3] = float("nan")
+    hip.sqnorm(gr, n, part)
+    hip.step_control(part, part.numel(), 1.0, 5e-5, 2, 10, 1, 0.9, 0.999, 1.0, ctrl)
+    hip.adamw(p, gr, m, v, pb, n, ctrl, 0.01, 0.9, 0.999, 1e-8)
+    assert torch.equal(p, before) and float(ctrl[1]) == 0.0 and float(ctrl[6]) == float(cb[6])
+
+
+def test_cast_axpy_gather(hip):
+    x = rnd(1000, seed=1)
+    y = torch.zeros(1000, dtype=torch.bfloat16, device=dev())
+    hip.cast_bf16(x, y, 1000)
+    assert torch.equal(y, x.bfloat16())
+    z = torch.ones(1000, device=dev())
+    hip.axpy(x, 0.5, z, 1000, accumulate=True)
+    assert torch.allclose(z, 1 + 0.5 * x)
+    src = rnd(20, 64, seed=2).bfloat16()
+    rmap = torch.tensor([3, 3, 19, 0], dtype=torch.int32, device=dev())
+    dst = torch.zeros(4, 64, dtype=torch.bfloat16, device=dev())
+    hip.gather_rows_bf16(src, rmap, 4, 64, dst)
+    assert torch.equal(dst, src[rmap.long()])
+
+
+def test_bad_arguments_raise(hip):
+    a = torch.zeros(8, 8, dtype=torch.bfloat16, device=dev())
+    with pytest.raises(RuntimeError, match="multiple of 8"):
+        hip.gemm(a, a, 8, 8, 4, 0, lda=8, ldb=8, out_f32=torch.zeros(8, 8, device=dev()))
+    with pytest.raises(RuntimeError, match="S must be"):
+        hip.attention_fwd(a, None, 1, 200, 1, True, a)
