@@ -166,6 +166,11 @@ int pgca_vit_assemble(const float* patch_embeds, const float* cls, const float* 
  * (mode 1; model.py:1082-1083; 0/0 = NaN when a caption has <= 1 real token, as the reference). */
 int pgca_seq_reduce(const float* tok_lp, const int32_t* seq_of_row, int32_t nrows, int32_t nseq,
                     const int32_t* seq_count, int32_t mode, float* seq_lp, void* stream);
+/* Token log-probs from MATERIALISED f32 logits (API-compatibility path of PreferenceLoss /
+ * compute_sequence_logprobs, model.py:1069-1079, components.py:340-354):
+ * out[r] = logits[row_map[r], targets[r]] - logsumexp(logits[row_map[r], 0:V]). */
+int pgca_logits_logprob(const float* logits, int32_t ld, int32_t V, const int32_t* row_map, const int64_t* targets,
+                        int32_t R, float* out, void* stream);
 /* DPO / preference loss over B pairs (components.py:210-231, model.py:1047-1048).
  * pol_w/pol_l/ref_w/ref_l f32 [B] (ref_* may be NULL = reference-free).
  * loss[0] = mean loss; dpol_w/dpol_l [B] = dLoss/dpol (f32); metrics[4] = reward_margin,

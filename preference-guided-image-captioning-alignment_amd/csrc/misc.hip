@@ -296,6 +296,23 @@ __global__ void gather_rows_bf16_kernel(const bf16_t* __restrict__ src, const in
   }
 }
 
+// tok_lp[r] = logits[row_map[r], targets[r]] - logsumexp(logits[row_map[r], :V]); one wave per row.
+// Compatibility path for callers that hold materialised [B,S,V] logits (reference model.py:1069-1079).
+__global__ void logits_logprob_kernel(const float* __restrict__ logits, int ld, int V, const int* __restrict__ row_map,
+                                      const long long* __restrict__ targets, int R, float* __restrict__ out) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const float* row = logits + (size_t)(row_map ? row_map[r] : r) * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, row[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += __expf(row[c] - mx);
+  s = wave_sum(s);
+  if (lane == 0) out[r] = row[targets[r]] - (mx + __logf(s));
+}
+
 inline int blocks_for(long long work, int per_block, int cap = 4096) {
   long long b = (work + per_block - 1) / per_block;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -432,4 +449,12 @@ extern "C" int pgca_gather_rows_bf16(const void* src, const int32_t* row_map, in
   hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(blocks_for((long long)M * H / 8, 256)), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_t*)src, row_map, M, H, (bf16_t*)dst);
   return check_launch("pgca_gather_rows_bf16");
+}
+
+extern "C" int pgca_logits_logprob(const float* logits, int32_t ld, int32_t V, const int32_t* row_map,
+                                   const int64_t* targets, int32_t R, float* out, void* stream) {
+  REQUIRE(logits && targets && out && R > 0 && V > 0 && ld >= V, "pgca_logits_logprob");
+  hipLaunchKernelGGL(logits_logprob_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, V,
+                     row_map, (const long long*)targets, R, out);
+  return check_launch("pgca_logits_logprob");
 }

@@ -1,0 +1,660 @@
+"""Forward/backward schedules of the towers on the HIP kernels (no autograd, no CPU fallback).
+
+Each class owns the launch order of one tower and the activations its backward needs.
+Activations live in a reusable ``Workspace`` sized once per batch geometry (288 GB of HBM:
+everything a backward needs is kept resident, nothing is recomputed except the LM-head
+logits tiles, which never reach HBM in the forward).
+
+Residual streams are f32 (as under the reference's autocast, where LayerNorm outputs and the
+residual adds stay f32); GEMM operands are bf16 with f32 MFMA accumulation.
+
+Reference call sites replaced are cited per method.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import hip
+from .arch import GptArch, ModelArch, VitArch
+from .params import ParamStore, Segment, VOCAB_TILE
+
+F32, BF16, I32, I64 = torch.float32, torch.bfloat16, torch.int32, torch.int64
+
+
+class Workspace:
+    """Named, reusable device buffers (allocated on first use, reused every step)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.bufs: Dict[str, torch.Tensor] = {}
+
+    def get(self, key: str, shape, dtype, zero: bool = False) -> torch.Tensor:
+        shape = tuple(int(s) for s in shape)
+        n = 1
+        for s in shape:
+            n *= s
+        t = self.bufs.get(key)
+        if t is None or t.dtype != dtype or t.numel() < n:
+            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            self.bufs[key] = t
+        v = t[:n].view(shape)
+        if zero:
+            v.zero_()
+        return v
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.bufs.values())
+
+
+# ------------------------------------------------------------------------------------------ batches
+@dataclass
+class SeqBatch:
+    """Token batch + the integer index work of the loss, prepared once per batch.
+
+    ``row_map[r]`` is the flat (b*S + t) hidden-state row whose logits score token
+    ``targets[r] = ids[b, t+1]``; only rows with ``mask[b, t+1] == 1`` are kept (the shift and the
+    mask product of reference model.py:1069-1083 / components.py:340-357).  Rows are sorted by
+    sequence, so a sequence's rows are contiguous.
+    """
+    ids: torch.Tensor          # [Bq, S] int64 (device)
+    mask: torch.Tensor         # [Bq, S] int32 (device)
+    row_map: torch.Tensor      # [Mc] int32
+    targets: torch.Tensor      # [Mc] int64  (bit-exact copy of labels[:, 1:] at the kept positions)
+    seq_of_row: torch.Tensor   # [Mc] int32
+    counts: torch.Tensor       # [Bq] int32  = sum(mask[:, 1:])
+    n_rows: int
+    Bq: int
+    S: int
+
+
+def make_seq_batch(ids: torch.Tensor, mask: torch.Tensor, device) -> SeqBatch:
+    """Host-side (collate-time) index preparation; ``ids``/``mask`` may be CPU or device tensors."""
+    ids_c = ids.detach().to("cpu", I64)
+    mask_c = mask.detach().to("cpu")
+    Bq, S = ids_c.shape
+    keep = mask_c[:, 1:] != 0
+    if not bool(keep.any()):
+        raise ValueError("no scored token in the batch (every caption has <= 1 real token)")
+    b_idx, t_idx = torch.nonzero(keep, as_tuple=True)            # row-major: sorted by sequence
+    row_map = (b_idx * S + t_idx).to(I32)
+    targets = ids_c[:, 1:][keep].contiguous()
+    counts = keep.sum(dim=1).to(I32)
+    n = int(row_map.numel())
+    dev = torch.device(device)
+    return SeqBatch(ids=ids_c.to(dev), mask=(mask_c != 0).to(I32).to(dev), row_map=row_map.to(dev),
+                    targets=targets.to(dev), seq_of_row=b_idx.to(I32).to(dev), counts=counts.to(dev),
+                    n_rows=n, Bq=Bq, S=S)
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _bias_grad(ws: Workspace, M: int, N: int, ld: int, gout: torch.Tensor, x_bf16=None, x_f32=None) -> None:
+    nb = hip.colsum_blocks(M)
+    part = ws.get("colsum_part", (nb, N), F32)
+    hip.colsum(M, N, ld, part, x_bf16=x_bf16, x_f32=x_f32)
+    hip.colsum_finish(part, nb, N, gout, accumulate=True)
+
+
+def _ln_param_grads(part: torch.Tensor, nb: int, H: int, gw: torch.Tensor, gb: torch.Tensor) -> None:
+    hip.colsum_finish(part[0], nb, H, gw, accumulate=True)
+    hip.colsum_finish(part[1], nb, H, gb, accumulate=True)
+
+
+class _P:
+    """Resolved views of one parameter: f32 master, bf16 mirror, gradient (if trainable)."""
+    __slots__ = ("w", "b", "g")
+
+    def __init__(self, seg: Segment, name: str):
+        self.w = seg.w(name)
+        self.b = seg.wb(name) if seg.bf16 is not None else None
+        self.g = seg.g(name) if seg.grad is not None else None
+
+
+# ------------------------------------------------------------------------------------------ GPT-2 trunk
+class GptTrunk:
+    """GPT-2 blocks + ln_f on an f32 residual stream (HF GPT2Block, modeling_gpt2.py:246-310).
+
+    Weights are Conv1D ``[in, out]``: forward is an NN GEMM, dgrad NT, wgrad TN - all from the
+    one bf16 mirror.  Dropout sites are identity (p = 0 / eval semantics).
+    """
+
+    def __init__(self, store: ParamStore, prefix: str, arch: GptArch, ws: Workspace, tag: str):
+        self.arch, self.ws, self.tag = arch, ws, tag
+        seg = store.seg_of(prefix + ".ln_f.weight")
+        self.seg = seg
+        self.layers = []
+        for i in range(arch.layers):
+            p = f"{prefix}.h.{i}"
+            self.layers.append({k: _P(seg, p + n) for k, n in (
+                ("ln1w", ".ln_1.weight"), ("ln1b", ".ln_1.bias"), ("wqkv", ".attn.c_attn.weight"),
+                ("bqkv", ".attn.c_attn.bias"), ("wo", ".attn.c_proj.weight"), ("bo", ".attn.c_proj.bias"),
+                ("ln2w", ".ln_2.weight"), ("ln2b", ".ln_2.bias"), ("wfc", ".mlp.c_fc.weight"),
+                ("bfc", ".mlp.c_fc.bias"), ("wpr", ".mlp.c_proj.weight"), ("bpr", ".mlp.c_proj.bias"))})
+        self.lnf_w, self.lnf_b = _P(seg, prefix + ".ln_f.weight"), _P(seg, prefix + ".ln_f.bias")
+        self.saved: Optional[dict] = None
+
+    def _buf(self, name, shape, dtype, zero=False):
+        return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
+
+    def forward(self, h0: torch.Tensor, mask: Optional[torch.Tensor], Bq: int, S: int, save: bool) -> torch.Tensor:
+        """h0 [Bq*S, H] f32 (already including positions) -> residual stream after the last block."""
+        a, H, I = self.arch, self.arch.hidden, self.arch.inner
+        M = Bq * S
+        L = len(self.layers)
+        sv = {"M": M, "Bq": Bq, "S": S, "mask": mask} if save else None
+        h = h0
+        for li, P in enumerate(self.layers):
+            k = f"l{li}." if save else ""
+            ln1 = self._buf(k + "ln1", (M, H), BF16)
+            m1 = self._buf(k + "m1", (M,), F32)
+            r1 = self._buf(k + "r1", (M,), F32)
+            hip.layernorm_fwd(h, M, H, P["ln1w"].w, P["ln1b"].w, a.eps, y_bf16=ln1, mean=m1, rstd=r1)
+            qkv = self._buf(k + "qkv", (M, 3 * H), BF16)
+            hip.gemm(ln1, P["wqkv"].b, M, 3 * H, H, hip.NN, bias=P["bqkv"].w, out_bf16=qkv)
+            att = self._buf(k + "att", (M, H), BF16)
+            lse = self._buf(k + "lse", (Bq, a.heads, S), F32)
+            hip.attention_fwd(qkv, mask, Bq, S, a.heads, True, att, lse)
+            hm = self._buf(k + "hm", (M, H), F32) if save else h
+            hip.gemm(att, P["wo"].b, M, H, H, hip.NN, bias=P["bo"].w, residual=h, out_f32=hm)
+            ln2 = self._buf(k + "ln2", (M, H), BF16)
+            m2 = self._buf(k + "m2", (M,), F32)
+            r2 = self._buf(k + "r2", (M,), F32)
+            hip.layernorm_fwd(hm, M, H, P["ln2w"].w, P["ln2b"].w, a.eps, y_bf16=ln2, mean=m2, rstd=r2)
+            act = self._buf(k + "act", (M, I), BF16)
+            pre = self._buf(k + "pre", (M, I), BF16) if save else None
+            hip.gemm(ln2, P["wfc"].b, M, I, H, hip.NN, epilogue=hip.EPI_GELU_NEW, bias=P["bfc"].w, out_bf16=act,
+                     aux_out=pre)
+            hn = self._buf(f"l{li + 1}.hin", (M, H), F32) if save else hm
+            hip.gemm(act, P["wpr"].b, M, H, I, hip.NN, bias=P["bpr"].w, residual=hm, out_f32=hn)
+            if save:
+                sv[li] = dict(hin=h, ln1=ln1, m1=m1, r1=r1, qkv=qkv, att=att, lse=lse, hm=hm, ln2=ln2, m2=m2, r2=r2,
+                              act=act, pre=pre)
+            h = hn
+        if save:
+            sv["hL"] = h
+            self.saved = sv
+        return h
+
+    def backward(self, g: torch.Tensor, g_bf: torch.Tensor) -> torch.Tensor:
+        """g / g_bf: dL/d(stream after last block) as f32 and bf16 [M, H]. Returns dL/dh0 (f32).
+        Weight/bias/LN gradients are ACCUMULATED into the segment's flat gradient buffer."""
+        sv = self.saved
+        assert sv is not None, "forward(save=True) must precede backward"
+        a, H, I = self.arch, self.arch.hidden, self.arch.inner
+        M, Bq, S = sv["M"], sv["Bq"], sv["S"]
+        ws = self.ws
+        nb = hip.layernorm_bwd_blocks(M)
+        part = ws.get("ln_part", (2, nb, H), F32)
+        for li in range(len(self.layers) - 1, -1, -1):
+            P, s = self.layers[li], sv[li]
+            # ---- MLP: h_out = hm + c_proj(gelu(c_fc(ln2(hm))))
+            dpre = self._buf("dpre", (M, I), BF16)
+            hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=s["pre"], out_bf16=dpre)
+            hip.gemm(s["act"], g_bf, I, H, M, hip.TN, lda=I, ldb=H, out_f32=P["wpr"].g, accumulate=True)
+            _bias_grad(ws, M, H, H, P["bpr"].g, x_f32=g)
+            dln = self._buf("dln", (M, H), BF16)
+            hip.gemm(dpre, P["wfc"].b, M, H, I, hip.NT, out_bf16=dln)
+            hip.gemm(s["ln2"], dpre, H, I, M, hip.TN, lda=H, ldb=I, out_f32=P["wfc"].g, accumulate=True)
+            _bias_grad(ws, M, I, I, P["bfc"].g, x_bf16=dpre)
+            g2 = self._buf("g_b" if (li & 1) else "g_a", (M, H), F32)
+            g2_bf = self._buf("gbf_b" if (li & 1) else "gbf_a", (M, H), BF16)
+            hip.layernorm_bwd(s["hm"], M, H, P["ln2w"].w, s["m2"], s["r2"], g2, dy_bf16=dln, add_to=g, dx_bf16=g2_bf,
+                              part=part)
+            _ln_param_grads(part, nb, H, P["ln2w"].g, P["ln2b"].g)
+            # ---- attention: hm = hin + c_proj(attn(c_attn(ln1(hin))))
+            datt = self._buf("datt", (M, H), BF16)
+            hip.gemm(g2_bf, P["wo"].b, M, H, H, hip.NT, out_bf16=datt)
+            hip.gemm(s["att"], g2_bf, H, H, M, hip.TN, lda=H, ldb=H, out_f32=P["wo"].g, accumulate=True)
+            _bias_grad(ws, M, H, H, P["bo"].g, x_f32=g2)
+            dqkv = self._buf("dqkv", (M, 3 * H), BF16)
+            hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], Bq, S, a.heads, True, dqkv)
+            hip.gemm(dqkv, P["wqkv"].b, M, H, 3 * H, hip.NT, out_bf16=dln)
+            hip.gemm(s["ln1"], dqkv, H, 3 * H, M, hip.TN, lda=H, ldb=3 * H, out_f32=P["wqkv"].g, accumulate=True)
+            _bias_grad(ws, M, 3 * H, 3 * H, P["bqkv"].g, x_bf16=dqkv)
+            g3 = self._buf("g_c" if (li & 1) else "g_d", (M, H), F32)
+            g3_bf = self._buf("gbf_c" if (li & 1) else "gbf_d", (M, H), BF16)
+            hip.layernorm_bwd(s["hin"], M, H, P["ln1w"].w, s["m1"], s["r1"], g3, dy_bf16=dln, add_to=g2,
+                              dx_bf16=g3_bf, part=part)
+            _ln_param_grads(part, nb, H, P["ln1w"].g, P["ln1b"].g)
+            g, g_bf = g3, g3_bf
+        return g
+
+
+# ------------------------------------------------------------------------------------------ projection heads
+class ProjHead:
+    """Linear -> ReLU -> Dropout(identity) -> Linear -> LayerNorm (reference model.py:136-142,338-344)."""
+
+    def __init__(self, store: ParamStore, prefix: str, in_dim: int, proj: int, ws: Workspace, tag: str):
+        seg = store.seg_of(prefix + ".0.weight")
+        self.seg, self.ws, self.tag, self.inn, self.P = seg, ws, tag, in_dim, proj
+        self.w0, self.b0 = _P(seg, prefix + ".0.weight"), _P(seg, prefix + ".0.bias")
+        self.w3, self.b3 = _P(seg, prefix + ".3.weight"), _P(seg, prefix + ".3.bias")
+        self.lnw, self.lnb = _P(seg, prefix + ".4.weight"), _P(seg, prefix + ".4.bias")
+        self.saved = None
+
+    def forward(self, x_bf: torch.Tensor, B: int, save: bool) -> torch.Tensor:
+        """x_bf [B, in] bf16 -> embeddings [B, P] f32 (un-normalised)."""
+        ws, t, Pd = self.ws, self.tag, self.P
+        h1 = ws.get(t + ".h1", (B, Pd), BF16)
+        hip.gemm(x_bf, self.w0.b, B, Pd, self.inn, hip.NT, epilogue=hip.EPI_RELU, bias=self.b0.w, out_bf16=h1)
+        h2 = ws.get(t + ".h2", (B, Pd), F32)
+        hip.gemm(h1, self.w3.b, B, Pd, Pd, hip.NT, bias=self.b3.w, out_f32=h2)
+        emb = ws.get(t + ".emb", (B, Pd), F32)
+        mean, rstd = ws.get(t + ".mean", (B,), F32), ws.get(t + ".rstd", (B,), F32)
+        hip.layernorm_fwd(h2, B, Pd, self.lnw.w, self.lnb.w, 1e-5, y_f32=emb, mean=mean, rstd=rstd)
+        if save:
+            self.saved = dict(x=x_bf, h1=h1, h2=h2, mean=mean, rstd=rstd, B=B)
+        return emb
+
+    def backward(self, demb: torch.Tensor, need_dx: bool) -> Optional[torch.Tensor]:
+        s, ws, t, Pd = self.saved, self.ws, self.tag, self.P
+        B = s["B"]
+        nb = hip.layernorm_bwd_blocks(B)
+        part = ws.get("ln_part_small", (2, nb, Pd), F32)
+        dh2 = ws.get(t + ".dh2", (B, Pd), F32)
+        dh2_bf = ws.get(t + ".dh2bf", (B, Pd), BF16)
+        hip.layernorm_bwd(s["h2"], B, Pd, self.lnw.w, s["mean"], s["rstd"], dh2, dy_f32=demb, dx_bf16=dh2_bf, part=part)
+        _ln_param_grads(part, nb, Pd, self.lnw.g, self.lnb.g)
+        # nn.Linear [out,in]: dW = dY^t X (TN), dX = dY W (NN)
+        hip.gemm(dh2_bf, s["h1"], Pd, Pd, B, hip.TN, lda=Pd, ldb=Pd, out_f32=self.w3.g, accumulate=True)
+        _bias_grad(ws, B, Pd, Pd, self.b3.g, x_f32=dh2)
+        dh1 = ws.get(t + ".dh1", (B, Pd), BF16)
+        hip.gemm(dh2_bf, self.w3.b, B, Pd, Pd, hip.NN, epilogue=hip.EPI_DRELU, aux_in=s["h1"], out_bf16=dh1)
+        hip.gemm(dh1, s["x"], Pd, self.inn, B, hip.TN, lda=Pd, ldb=self.inn, out_f32=self.w0.g, accumulate=True)
+        _bias_grad(ws, B, Pd, Pd, self.b0.g, x_bf16=dh1)
+        if not need_dx:
+            return None
+        dx = ws.get(t + ".dx", (B, self.inn), F32)
+        hip.gemm(dh1, self.w0.b, B, self.inn, Pd, hip.NN, out_f32=dx)
+        return dx
+
+
+# ------------------------------------------------------------------------------------------ ViT (frozen)
+class VisionTower:
+    """CLIP vision transformer forward (HF CLIPVisionTransformer, modeling_clip.py:200-218,353-384,
+    594-650) as called at reference model.py:222-230.  Forward only: the tower is frozen in every
+    shipped config (configs/default.yaml:23) and is run ONCE per image per step."""
+
+    def __init__(self, store: ParamStore, arch: VitArch, ws: Workspace):
+        self.arch, self.ws = arch, ws
+        p = "vision_encoder.vision_model"
+        seg = store.seg_of(p + ".post_layernorm.weight")
+        self.seg = seg
+        self.cls = seg.w(p + ".embeddings.class_embedding")
+        self.pos = seg.w(p + ".embeddings.position_embedding.weight")
+        self.wpatch = seg.wb(p + ".embeddings.patch_embedding.weight")
+        self.pre = (seg.w(p + ".pre_layrnorm.weight"), seg.w(p + ".pre_layrnorm.bias"))
+        self.post = (seg.w(p + ".post_layernorm.weight"), seg.w(p + ".post_layernorm.bias"))
+        H = arch.hidden
+        self.layers = []
+        for i in range(arch.layers):
+            q = f"{p}.encoder.layers.{i}"
+            wq_off = seg.index[q + ".self_attn.q_proj.weight"][0]
+            bq_off = seg.index[q + ".self_attn.q_proj.bias"][0]
+            assert seg.index[q + ".self_attn.v_proj.weight"][0] == wq_off + 2 * H * H, "q,k,v must be contiguous"
+            assert seg.index[q + ".self_attn.v_proj.bias"][0] == bq_off + 2 * H
+            self.layers.append(dict(
+                wqkv=seg.bf16[wq_off:wq_off + 3 * H * H].view(3 * H, H), bqkv=seg.fp32[bq_off:bq_off + 3 * H],
+                wo=seg.wb(q + ".self_attn.out_proj.weight"), bo=seg.w(q + ".self_attn.out_proj.bias"),
+                ln1=(seg.w(q + ".layer_norm1.weight"), seg.w(q + ".layer_norm1.bias")),
+                ln2=(seg.w(q + ".layer_norm2.weight"), seg.w(q + ".layer_norm2.bias")),
+                w1=seg.wb(q + ".mlp.fc1.weight"), b1=seg.w(q + ".mlp.fc1.bias"),
+                w2=seg.wb(q + ".mlp.fc2.weight"), b2=seg.w(q + ".mlp.fc2.bias")))
+
+    def forward(self, pixels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """pixels [B,3,I,I] f32 -> (features [B,T,H] f32, pooled [B,H] f32, pooled bf16)."""
+        a, ws = self.arch, self.ws
+        B = pixels.shape[0]
+        H, T, G, D = a.hidden, a.tokens, a.grid, a.patch_dim
+        M = B * T
+        cols = ws.get("vit.cols", (B * G * G, D), BF16)
+        hip.patchify(pixels, B, a.image, a.patch, cols)
+        pe = ws.get("vit.pe", (B * G * G, H), F32)
+        hip.gemm(cols, self.wpatch, B * G * G, H, D, hip.NT, out_f32=pe)
+        x0 = ws.get("vit.x0", (M, H), F32)
+        hip.vit_assemble(pe, self.cls, self.pos, B, T, H, x0)
+        x = ws.get("vit.x", (M, H), F32)
+        hip.layernorm_fwd(x0, M, H, self.pre[0], self.pre[1], a.eps, y_f32=x)
+        y = ws.get("vit.y", (M, H), BF16)
+        qkv = ws.get("vit.qkv", (M, 3 * H), BF16)
+        att = ws.get("vit.att", (M, H), BF16)
+        act = ws.get("vit.act", (M, a.mlp), BF16)
+        for Lw in self.layers:
+            hip.layernorm_fwd(x, M, H, Lw["ln1"][0], Lw["ln1"][1], a.eps, y_bf16=y)
+            hip.gemm(y, Lw["wqkv"], M, 3 * H, H, hip.NT, bias=Lw["bqkv"], out_bf16=qkv)
+            hip.attention_fwd(qkv, None, B, T, a.heads, False, att, None)
+            hip.gemm(att, Lw["wo"], M, H, H, hip.NT, bias=Lw["bo"], residual=x, out_f32=x)
+            hip.layernorm_fwd(x, M, H, Lw["ln2"][0], Lw["ln2"][1], a.eps, y_bf16=y)
+            hip.gemm(y, Lw["w1"], M, a.mlp, H, hip.NT, epilogue=hip.EPI_QUICK_GELU, bias=Lw["b1"], out_bf16=act)
+            hip.gemm(act, Lw["w2"], M, H, a.mlp, hip.NT, bias=Lw["b2"], residual=x, out_f32=x)
+        cls_rows = ws.bufs.get("vit.clsrows")
+        if cls_rows is None or cls_rows.numel() != B:
+            cls_rows = (torch.arange(B, dtype=I32, device=ws.device) * T).contiguous()
+            ws.bufs["vit.clsrows"] = cls_rows
+        pooled = ws.get("vit.pooled", (B, H), F32)
+        pooled_bf = ws.get("vit.pooledbf", (B, H), BF16)
+        hip.layernorm_fwd(x, B, H, self.post[0], self.post[1], a.eps, row_map=cls_rows, y_f32=pooled, y_bf16=pooled_bf)
+        return x.view(B, T, H), pooled, pooled_bf
+
+
+# ------------------------------------------------------------------------------------------ caption decoder
+class CaptionDecoderEngine:
+    """Reference ``CaptionDecoder.forward`` (model.py:583-610) + tied LM head + log-prob gather
+    (model.py:1069-1083 / components.py:340-362), fused so the [B,S,V] logits never reach HBM.
+
+    The 1-token cross-attention is collapsed: softmax over one key is 1, so
+    ``attended[b, s, :] = W_o (W_v pv_b + b_v) + b_o`` for every s; q/k rows of ``in_proj`` receive
+    exactly zero gradient, as in the reference.
+    """
+
+    LM_CHUNK = 4096  # rows of dlogits materialised at a time in the LM-head backward (bf16 workspace)
+
+    def __init__(self, store: ParamStore, arch: ModelArch, ws: Workspace, tag: str):
+        self.arch, self.ws, self.tag = arch, ws, tag
+        g = arch.gpt
+        p = "caption_decoder"
+        t = p + ".lm_model.transformer"
+        seg = store.seg_of(t + ".wte.weight")
+        self.seg = seg
+        self.trunk = GptTrunk(store, t, g, ws, tag + ".trunk")
+        self.wte, self.wpe = _P(seg, t + ".wte.weight"), _P(seg, t + ".wpe.weight")
+        self.V = arch.dec_vocab
+        self.Vp = (self.V + VOCAB_TILE - 1) // VOCAB_TILE * VOCAB_TILE
+        self.wte_pad_bf = seg.padded(seg.bf16, t + ".wte.weight")          # [Vp, H], pad rows are zero
+        self.vp_w, self.vp_b = _P(seg, p + ".vision_projection.0.weight"), _P(seg, p + ".vision_projection.0.bias")
+        self.inw, self.inb = _P(seg, p + ".cross_attention.in_proj_weight"), _P(seg, p + ".cross_attention.in_proj_bias")
+        self.ow, self.ob = _P(seg, p + ".cross_attention.out_proj.weight"), _P(seg, p + ".cross_attention.out_proj.bias")
+        self.anw, self.anb = _P(seg, p + ".attention_norm.weight"), _P(seg, p + ".attention_norm.bias")
+        self.saved = None
+
+    def _buf(self, name, shape, dtype, zero=False):
+        return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
+
+    # -- forward --------------------------------------------------------------------------------
+    def _prefix(self, emb: torch.Tensor, Bq: int):
+        """emb [Bq, P] f32 -> attended [Bq, H] f32 (+ saved intermediates)."""
+        H, Pd = self.arch.gpt.hidden, self.arch.proj_dim
+        emb_bf = self._buf("emb_bf", (Bq, Pd), BF16)
+        hip.cast_bf16(emb, emb_bf, Bq * Pd)
+        pv = self._buf("pv", (Bq, H), BF16)
+        hip.gemm(emb_bf, self.vp_w.b, Bq, H, Pd, hip.NT, epilogue=hip.EPI_TANH, bias=self.vp_b.w, out_bf16=pv)
+        vv = self._buf("vv", (Bq, H), BF16)
+        hip.gemm(pv, self.inw.b[2 * H:], Bq, H, H, hip.NT, bias=self.inb.w[2 * H:], out_bf16=vv)
+        att = self._buf("attended", (Bq, H), F32)
+        hip.gemm(vv, self.ow.b, Bq, H, H, hip.NT, bias=self.ob.w, out_f32=att)
+        return emb_bf, pv, vv, att
+
+    def hidden(self, emb: torch.Tensor, sb: SeqBatch, save: bool) -> torch.Tensor:
+        """Residual stream after the last block, [Bq*S, H] f32."""
+        a = self.arch.gpt
+        H, Bq, S = a.hidden, sb.Bq, sb.S
+        M = Bq * S
+        emb_bf, pv, vv, att = self._prefix(emb, Bq)
+        h0 = self._buf("h0", (M, H), F32)
+        m0, r0 = self._buf("m0", (M,), F32), self._buf("r0", (M,), F32)
+        hip.embed_fwd(sb.ids, Bq, S, H, self.wte.w, self.wpe.w, h0, attended=att, gamma=self.anw.w, beta=self.anb.w,
+                      eps=1e-5, mean=m0, rstd=r0)
+        hL = self.trunk.forward(h0, sb.mask, Bq, S, save)
+        if save:
+            self.saved = dict(sb=sb, emb_bf=emb_bf, pv=pv, vv=vv, att=att, m0=m0, r0=r0, hL=hL)
+        return hL
+
+    def token_logprobs(self, hL: torch.Tensor, sb: SeqBatch, save: bool) -> torch.Tensor:
+        """ln_f on the scored rows only, then the fused LM head: tok_lp [Mc] f32."""
+        a = self.arch.gpt
+        H, Mc = a.hidden, sb.n_rows
+        hf = self._buf("hf", (Mc, H), BF16)
+        mf, rf = self._buf("mf", (Mc,), F32), self._buf("rf", (Mc,), F32)
+        hip.layernorm_fwd(hL, Mc, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, row_map=sb.row_map, y_bf16=hf,
+                          mean=mf, rstd=rf)
+        nparts = 2 * (self.Vp // 128)
+        smax = self._buf("smax", (Mc, nparts), F32)
+        ssum = self._buf("ssum", (Mc, nparts), F32)
+        tval = self._buf("tval", (Mc,), F32)
+        hip.gemm(hf, self.wte.b, Mc, self.V, H, hip.NT, epilogue=hip.EPI_ROWSTATS, targets=sb.targets, stat_max=smax,
+                 stat_sum=ssum, stat_ld=nparts, target_val=tval)
+        lse = self._buf("lse", (Mc,), F32)
+        tok = self._buf("tok_lp", (Mc,), F32)
+        hip.rowstats_combine(smax, ssum, nparts, 2 * ((self.V + 127) // 128), tval, Mc, lse=lse, out_logprob=tok)
+        if save:
+            self.saved.update(hf=hf, mf=mf, rf=rf, lse=lse)
+        return tok
+
+    def sequence_logprobs(self, emb: torch.Tensor, sb: SeqBatch, reduce: str, save: bool) -> torch.Tensor:
+        """seq_lp [Bq]: 'sum' (components.py:357-362) or 'mean' (model.py:1082-1083)."""
+        hL = self.hidden(emb, sb, save)
+        tok = self.token_logprobs(hL, sb, save)
+        out = self._buf("seq_lp", (sb.Bq,), F32)
+        hip.seq_reduce(tok, sb.seq_of_row, sb.n_rows, sb.Bq, sb.counts, 1 if reduce == "mean" else 0, out)
+        if save:
+            self.saved["reduce"] = reduce
+        return out
+
+    def logits(self, emb: torch.Tensor, sb: SeqBatch) -> torch.Tensor:
+        """Materialised logits [Bq, S, V] f32 for API compatibility (``mode='generation'``)."""
+        a = self.arch.gpt
+        H, M = a.hidden, sb.Bq * sb.S
+        hL = self.hidden(emb, sb, False)
+        hf = self._buf("hf_full", (M, H), BF16)
+        hip.layernorm_fwd(hL, M, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_bf16=hf)
+        out = torch.empty(M, self.V, dtype=F32, device=self.ws.device)
+        hip.gemm(hf, self.wte.b, M, self.V, H, hip.NT, out_f32=out)
+        return out.view(sb.Bq, sb.S, self.V)
+
+    # -- backward -------------------------------------------------------------------------------
+    def backward(self, dseq: torch.Tensor) -> torch.Tensor:
+        """dseq [Bq] = dLoss/dseq_lp.  Accumulates all decoder gradients; returns dLoss/demb [Bq, P] f32."""
+        s = self.saved
+        sb: SeqBatch = s["sb"]
+        a = self.arch.gpt
+        H, Pd, Bq, S, Mc = a.hidden, self.arch.proj_dim, sb.Bq, sb.S, sb.n_rows
+        M = Bq * S
+        ws = self.ws
+        rs = self._buf("row_scale", (Mc,), F32)
+        hip.row_scale(dseq, sb.seq_of_row, sb.counts, Mc, 1 if s["reduce"] == "mean" else 0, rs)
+        # LM head: dlogits = g * (softmax - onehot), recomputed tile by tile in row chunks
+        dhf = self._buf("dhf", (Mc, H), BF16)
+        ck = min(self.LM_CHUNK, Mc)
+        dl = self._buf("dlogits", (ck, self.Vp), BF16)
+        for r0 in range(0, Mc, ck):
+            n = min(ck, Mc - r0)
+            hfc = s["hf"][r0:r0 + n]
+            hip.gemm(hfc, self.wte.b, n, self.V, H, hip.NT, epilogue=hip.EPI_DLOGITS, targets=sb.targets[r0:r0 + n],
+                     row_lse=s["lse"][r0:r0 + n], row_scale=rs[r0:r0 + n], out_bf16=dl, ld_out_bf16=self.Vp,
+                     out_cols=self.Vp)
+            hip.gemm(dl, self.wte_pad_bf, n, H, self.Vp, hip.NN, lda=self.Vp, ldb=H, out_bf16=dhf[r0:r0 + n])
+            hip.gemm(dl, hfc, self.V, H, n, hip.TN, lda=self.Vp, ldb=H, out_f32=self.wte.g, accumulate=True)
+        # ln_f backward scatters to the scored rows; every other row of the stream gets zero gradient
+        g = self.trunk._buf("g_top", (M, H), F32, zero=True)
+        g_bf = self.trunk._buf("gbf_top", (M, H), BF16, zero=True)
+        nb = hip.layernorm_bwd_blocks(Mc)
+        part = ws.get("ln_part_f", (2, nb, H), F32)
+        hip.layernorm_bwd(s["hL"], Mc, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_bf16=dhf, row_map=sb.row_map,
+                          dx_bf16=g_bf, part=part)
+        _ln_param_grads(part, nb, H, self.trunk.lnf_w.g, self.trunk.lnf_b.g)
+        g0 = self.trunk.backward(g, g_bf)
+        # embedding + attention_norm + collapsed cross-attention
+        datt = self._buf("datt", (Bq, H), F32, zero=True)
+        nbe = hip.embed_bwd_blocks(Bq, S)
+        parte = ws.get("ln_part_e", (2, nbe, H), F32)
+        hip.embed_bwd(g0, sb.ids, sb.mask, Bq, S, H, self.wte.g, self.wpe.g, wte=self.wte.w, attended=s["att"],
+                      gamma=self.anw.w, mean=s["m0"], rstd=s["r0"], dattended=datt, part=parte)
+        _ln_param_grads(parte, nbe, H, self.anw.g, self.anb.g)
+        datt_bf = self._buf("datt_bf", (Bq, H), BF16)
+        hip.cast_bf16(datt, datt_bf, Bq * H)
+        # attended = vv W_o^t + b_o
+        hip.gemm(datt_bf, s["vv"], H, H, Bq, hip.TN, lda=H, ldb=H, out_f32=self.ow.g, accumulate=True)
+        _bias_grad(ws, Bq, H, H, self.ob.g, x_f32=datt)
+        dvv = self._buf("dvv", (Bq, H), BF16)
+        hip.gemm(datt_bf, self.ow.b, Bq, H, H, hip.NN, out_bf16=dvv)
+        # vv = pv W_v^t + b_v   (value rows of in_proj; q/k rows keep zero gradient)
+        hip.gemm(dvv, s["pv"], H, H, Bq, hip.TN, lda=H, ldb=H, out_f32=self.inw.g[2 * H:], accumulate=True)
+        _bias_grad(ws, Bq, H, H, self.inb.g[2 * H:], x_bf16=dvv)
+        dpv = self._buf("dpv", (Bq, H), BF16)
+        hip.gemm(dvv, self.inw.b[2 * H:], Bq, H, H, hip.NN, epilogue=hip.EPI_DTANH, aux_in=s["pv"], out_bf16=dpv)
+        # pv = tanh(emb W_vp^t + b_vp)
+        hip.gemm(dpv, s["emb_bf"], H, Pd, Bq, hip.TN, lda=H, ldb=Pd, out_f32=self.vp_w.g, accumulate=True)
+        _bias_grad(ws, Bq, H, H, self.vp_b.g, x_bf16=dpv)
+        demb = self._buf("demb", (Bq, Pd), F32)
+        hip.gemm(dpv, self.vp_w.b, Bq, Pd, H, hip.NN, out_f32=demb)
+        return demb
+
+
+# ------------------------------------------------------------------------------------------ text tower (Stage 1)
+class TextTowerEngine:
+    """Reference ``TextEncoder.forward`` (model.py:437-474): GPT2Model -> masked mean pool -> head."""
+
+    def __init__(self, store: ParamStore, arch: ModelArch, ws: Workspace, tag: str):
+        self.arch, self.ws, self.tag = arch, ws, tag
+        t = "text_encoder.text_model"
+        seg = store.seg_of(t + ".wte.weight")
+        self.seg = seg
+        self.trunk = GptTrunk(store, t, arch.gpt, ws, tag + ".trunk")
+        self.wte, self.wpe = _P(seg, t + ".wte.weight"), _P(seg, t + ".wpe.weight")
+        self.head = ProjHead(store, "text_encoder.projection", arch.gpt.hidden, arch.proj_dim, ws, tag + ".head")
+        self.saved = None
+
+    def _buf(self, name, shape, dtype, zero=False):
+        return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
+
+    def forward(self, ids: torch.Tensor, mask: torch.Tensor, save: bool):
+        """ids int64 [B,S], mask int32 [B,S] (device) -> (features [B,S,H] f32, pooled [B,H] f32, emb [B,P] f32)."""
+        a = self.arch.gpt
+        B, S = ids.shape
+        H, M = a.hidden, B * S
+        h0 = self._buf("h0", (M, H), F32)
+        hip.embed_fwd(ids, B, S, H, self.wte.w, self.wpe.w, h0)
+        hL = self.trunk.forward(h0, mask, B, S, save)
+        feats = self._buf("feats", (M, H), F32)
+        mf, rf = self._buf("mf", (M,), F32), self._buf("rf", (M,), F32)
+        hip.layernorm_fwd(hL, M, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_f32=feats, mean=mf, rstd=rf)
+        pooled = self._buf("pooled", (B, H), F32)
+        hip.masked_mean_fwd(feats, mask, B, S, H, pooled)
+        pooled_bf = self._buf("pooled_bf", (B, H), BF16)
+        hip.cast_bf16(pooled, pooled_bf, B * H)
+        emb = self.head.forward(pooled_bf, B, save)
+        if save:
+            self.saved = dict(ids=ids, mask=mask, hL=hL, mf=mf, rf=rf, B=B, S=S)
+        return feats.view(B, S, H), pooled, emb
+
+    def backward(self, demb: torch.Tensor) -> None:
+        s, a, ws = self.saved, self.arch.gpt, self.ws
+        B, S, H = s["B"], s["S"], a.hidden
+        M = B * S
+        dpooled = self.head.backward(demb, need_dx=True)
+        dfeats = self._buf("dfeats", (M, H), F32)
+        hip.masked_mean_bwd(dpooled, s["mask"], B, S, H, dfeats)
+        g = self.trunk._buf("g_top", (M, H), F32)
+        g_bf = self.trunk._buf("gbf_top", (M, H), BF16)
+        nb = hip.layernorm_bwd_blocks(M)
+        part = ws.get("ln_part_f", (2, nb, H), F32)
+        hip.layernorm_bwd(s["hL"], M, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dfeats, dx_bf16=g_bf, part=part)
+        _ln_param_grads(part, nb, H, self.trunk.lnf_w.g, self.trunk.lnf_b.g)
+        g0 = self.trunk.backward(g, g_bf)
+        hip.embed_bwd(g0, s["ids"], s["mask"], B, S, H, self.wte.g, self.wpe.g)
+
+
+# ------------------------------------------------------------------------------------------ NT-Xent (Stage 1 loss)
+class NTXentEngine:
+    """Reference ``ContrastiveLoss.forward`` (model.py:984-1000) on F.normalize'd embeddings
+    (model.py:828-829), fused: the [N, N] similarity matrix is never materialised in f32 - each
+    128x128 tile yields per-row (max, sum exp) partials (ROWSTATS epilogue) for the rows of S
+    (image->text) and of S^t (text->image).
+
+    With data-parallel global negatives, rank r owns rows ``[off, off+B)`` of S and of S^t: it
+    scores its B images against all N texts and its B texts against all N images, so its local
+    gradient is complete given the gathered embeddings and the gathered row/column log-sum-exps
+    (2N floats) - no gradient collective.
+    """
+
+    def __init__(self, ws: Workspace, proj_dim: int, temperature: float, tag: str = "ntx"):
+        self.ws, self.P, self.tau, self.tag = ws, proj_dim, float(temperature), tag
+        self.saved = None
+
+    def _buf(self, name, shape, dtype, zero=False):
+        return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
+
+    def normalize(self, emb: torch.Tensor, which: str):
+        B, P = emb.shape
+        y, n = self._buf(which + ".y", (B, P), F32), self._buf(which + ".n", (B,), F32)
+        hip.l2norm_fwd(emb, B, P, y, n)
+        return y, n
+
+    def _stats(self, a_bf, b_all_bf, B, N, targets, which):
+        nparts = 2 * ((N + 127) // 128)
+        smax, ssum = self._buf(which + ".smax", (B, nparts), F32), self._buf(which + ".ssum", (B, nparts), F32)
+        tval, lse = self._buf(which + ".tval", (B,), F32), self._buf(which + ".lse", (B,), F32)
+        hip.gemm(a_bf, b_all_bf, B, N, self.P, hip.NT, epilogue=hip.EPI_ROWSTATS, alpha=1.0 / self.tau,
+                 targets=targets, stat_max=smax, stat_sum=ssum, stat_ld=nparts, target_val=tval)
+        hip.rowstats_combine(smax, ssum, nparts, nparts, tval, B, lse=lse)
+        return lse, tval
+
+    def forward(self, img_n: torch.Tensor, txt_n: torch.Tensor, img_all: Optional[torch.Tensor] = None,
+                txt_all: Optional[torch.Tensor] = None, offset: int = 0):
+        """Normalised local embeddings [B,P] f32 (+ gathered [N,P] when data parallel).
+        Returns (local loss contribution already divided by 2N, lse_r [B], lse_c [B])."""
+        B, P = img_n.shape
+        img_all = img_n if img_all is None else img_all
+        txt_all = txt_n if txt_all is None else txt_all
+        N = img_all.shape[0]
+        bf = {}
+        Np = (N + 7) // 8 * 8  # gathered tables are zero-padded to a multiple of 8 rows (K of the dgrad GEMMs)
+        for k, t, rows in (("i", img_n, B), ("t", txt_n, B), ("ia", img_all, Np), ("ta", txt_all, Np)):
+            bf[k] = self._buf("bf." + k, (rows, P), BF16, zero=(rows != t.shape[0]))
+            hip.cast_bf16(t, bf[k], t.numel())
+        tg = self.ws.bufs.get(self.tag + ".targets")
+        if tg is None or tg.numel() != B or int(tg[0]) != offset:
+            tg = (torch.arange(B, dtype=I64, device=self.ws.device) + offset).contiguous()
+            self.ws.bufs[self.tag + ".targets"] = tg
+        lse_r, diag = self._stats(bf["i"], bf["ta"], B, N, tg, "r")
+        lse_c, _ = self._stats(bf["t"], bf["ia"], B, N, tg, "c")
+        loss = self._buf("loss", (1,), F32)
+        hip.ntxent_loss(lse_r, lse_c, diag, B, N, loss)
+        self.saved = dict(bf=bf, B=B, N=N, offset=offset, lse_r=lse_r, lse_c=lse_c, tg=tg)
+        return loss, lse_r, lse_c
+
+    def backward(self, lse_r_all: Optional[torch.Tensor] = None, lse_c_all: Optional[torch.Tensor] = None,
+                 loss_scale: float = 1.0):
+        """Returns (d loss / d img_n, d loss / d txt_n) [B,P] f32 for the LOCAL rows."""
+        s, P = self.saved, self.P
+        B, N, off, bf = s["B"], s["N"], s["offset"], s["bf"]
+        lse_r_all = s["lse_r"] if lse_r_all is None else lse_r_all
+        lse_c_all = s["lse_c"] if lse_c_all is None else lse_c_all
+        c = loss_scale / (2.0 * N)
+        inv_tau = 1.0 / self.tau
+        Np = (N + 7) // 8 * 8
+        Bp = (B + 7) // 8 * 8
+        cB = self._buf("cB", (B,), F32)
+        cB.fill_(c)
+        cN = self._buf("cN", (N,), F32)
+        cN.fill_(c)
+        tgN = self.ws.bufs.get(self.tag + ".targetsN")
+        if tgN is None or tgN.numel() != N or s["offset"] != getattr(self, "_tgN_off", None):
+            j = torch.arange(N, dtype=I64, device=self.ws.device) - off
+            tgN = torch.where((j >= 0) & (j < B), j, torch.full_like(j, -1)).contiguous()
+            self.ws.bufs[self.tag + ".targetsN"] = tgN
+            self._tgN_off = off
+        # G1[i in loc, j in all] = c (p^r_ij - d_ij);  G2[j in loc, i in all] = c (p^c_ij - d_ij)
+        g1 = self._buf("g1", (B, Np), BF16)
+        g2 = self._buf("g2", (B, Np), BF16)
+        hip.gemm(bf["i"], bf["ta"], B, N, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
+                 row_lse=s["lse_r"], row_scale=cB, out_bf16=g1, ld_out_bf16=Np, out_cols=Np)
+        hip.gemm(bf["t"], bf["ia"], B, N, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
+                 row_lse=s["lse_c"], row_scale=cB, out_bf16=g2, ld_out_bf16=Np, out_cols=Np)
+        # G1'[i in all, j in loc] = c (p^r_ij - d_ij);  G2'[j in all, i in loc] = c (p^c_ij - d_ij)
+        g1t = self._buf("g1t", (N, Bp), BF16)
+        g2t = self._buf("g2t", (N, Bp), BF16)
+        hip.gemm(bf["ia"], bf["t"], N, B, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
+                 row_lse=lse_r_all, row_scale=cN, out_bf16=g1t, ld_out_bf16=Bp, out_cols=Bp)
+        hip.gemm(bf["ta"], bf["i"], N, B, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
+                 row_lse=lse_c_all, row_scale=cN, out_bf16=g2t, ld_out_bf16=Bp, out_cols=Bp)
+        dI = self._buf("dI", (B, P), F32)
+        dT = self._buf("dT", (B, P), F32)
+        # dI_loc = (1/tau) (G1 T_all + G2'^t T_all);  dT_loc = (1/tau) (G2 I_all + G1'^t I_all)
+        hip.gemm(g1, bf["ta"], B, P, Np, hip.NN, lda=Np, ldb=P, alpha=inv_tau, out_f32=dI)
+        hip.gemm(g2t, bf["ta"], B, P, N, hip.TN, lda=Bp, ldb=P, alpha=inv_tau, out_f32=dI, accumulate=True)
+        hip.gemm(g2, bf["ia"], B, P, Np, hip.NN, lda=Np, ldb=P, alpha=inv_tau, out_f32=dT)
+        hip.gemm(g1t, bf["ia"], B, P, N, hip.TN, lda=Bp, ldb=P, alpha=inv_tau, out_f32=dT, accumulate=True)
+        return dI, dT

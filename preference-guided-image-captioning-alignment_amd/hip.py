@@ -59,6 +59,7 @@ _SIGS = {
     "pgca_patchify": [_vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_vit_assemble": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_seq_reduce": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
+    "pgca_logits_logprob": [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
     "pgca_dpo_loss": [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_row_scale": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "pgca_masked_mean_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -214,6 +215,11 @@ def vit_assemble(patch_embeds, cls, pos, B, T, H, x):
 def seq_reduce(tok_lp, seq_of_row, nrows, nseq, seq_count, mode, seq_lp):
     _check(load().pgca_seq_reduce(_p(tok_lp), _p(seq_of_row), nrows, nseq, _p(seq_count), mode, _p(seq_lp),
                                   _stream()), "pgca_seq_reduce")
+
+
+def logits_logprob(logits, ld, V, row_map, targets, R, out):
+    _check(load().pgca_logits_logprob(_p(logits), ld, V, _p(row_map), _p(targets), R, _p(out), _stream()),
+           "pgca_logits_logprob")
 
 
 def dpo_loss(pol_w, pol_l, ref_w, ref_l, B, beta, label_smoothing, loss, dpol_w=None, dpol_l=None, metrics=None):

@@ -1,0 +1,222 @@
+"""The reference's Python surface for the hot path, backed by the HIP engines.
+
+Same constructor arguments, ``forward`` signature, output-dict keys, sub-module names and
+error behaviour as reference ``models/model.py`` (``PreferenceGuidedCaptioningModel`` :740-853,
+``VisionEncoder.forward`` :166-243, ``TextEncoder.forward`` :402-474, ``CaptionDecoder.forward``
+:561-619).  Tensors returned are plain device tensors: gradients are produced by the explicit
+backward schedules in ``steps.py`` (``DPOStep`` / ``ContrastiveStep``), not by autograd.
+
+Not implemented (out of the hot path): LoRA adapters, ``generate``.
+Dropout sites run as identity (the reference's eval-mode arithmetic); see DESIGN.md.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import hip
+from .arch import ModelArch, make_arch
+from .engine import (BF16, F32, I32, I64, CaptionDecoderEngine, ProjHead, SeqBatch, TextTowerEngine, VisionTower,
+                     Workspace, make_seq_batch)
+from .params import ParamStore
+
+logger = logging.getLogger(__name__)
+
+
+def _default_device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("pgca_amd needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class VisionEncoder:
+    """Frozen CLIP ViT + trainable projection head (reference model.py:64-243)."""
+
+    def __init__(self, owner: "PreferenceGuidedCaptioningModel"):
+        self._o = owner
+        self.projection_dim = owner.projection_dim
+        self.feature_dim = owner.arch.vit.hidden
+        self.freeze_backbone = True
+        self.tower = VisionTower(owner.store, owner.arch.vit, owner.ws)
+        self.head = ProjHead(owner.store, "vision_encoder.projection", owner.arch.vit.hidden, owner.arch.proj_dim,
+                             owner.ws, "vhead")
+
+    def forward(self, pixel_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        if pixel_values.dim() != 4:
+            raise ValueError(f"Expected pixel_values to be 4D tensor (B, C, H, W), got {pixel_values.dim()}D")
+        if pixel_values.size(1) != 3:
+            raise ValueError(f"Expected 3 channels (RGB), got {pixel_values.size(1)} channels")
+        try:
+            px = pixel_values.to(self._o.device, F32).contiguous()
+            feats, pooled, pooled_bf = self.tower.forward(px)
+        except Exception as e:  # same wrapping as reference model.py:232-234
+            raise RuntimeError(f"Vision encoding failed: {e}") from e
+        emb = self.head.forward(pooled_bf, px.shape[0], save=False)
+        return {"features": feats, "embeddings": emb, "pooled_output": pooled}
+
+    __call__ = forward
+
+
+class TextEncoder:
+    """GPT-2 text tower + projection head (reference model.py:246-474)."""
+
+    def __init__(self, owner: "PreferenceGuidedCaptioningModel"):
+        self._o = owner
+        self.projection_dim = owner.projection_dim
+        self.feature_dim = owner.arch.gpt.hidden
+        self.engine = TextTowerEngine(owner.store, owner.arch, owner.ws, "text")
+
+    def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
+                return_hidden_states: bool = False) -> Dict[str, torch.Tensor]:
+        if input_ids.dim() != 2:
+            raise ValueError(f"Expected input_ids to be 2D tensor (B, seq_len), got {input_ids.dim()}D")
+        if attention_mask.dim() != 2:
+            raise ValueError(f"Expected attention_mask to be 2D tensor (B, seq_len), got {attention_mask.dim()}D")
+        if input_ids.shape != attention_mask.shape:
+            raise ValueError(
+                f"input_ids shape {input_ids.shape} doesn't match attention_mask shape {attention_mask.shape}")
+        try:
+            dev = self._o.device
+            ids = input_ids.to(dev, I64).contiguous()
+            mask = (attention_mask != 0).to(I32).to(dev).contiguous()
+            feats, pooled, emb = self.engine.forward(ids, mask, save=False)
+        except Exception as e:  # reference model.py:458-460
+            raise RuntimeError(f"Text encoding failed: {e}") from e
+        return {"features": feats, "embeddings": emb, "pooled_output": pooled}
+
+    __call__ = forward
+
+
+class CaptionDecoder:
+    """GPT-2 caption decoder with the collapsed 1-token cross-attention (reference model.py:477-619)."""
+
+    def __init__(self, owner: "PreferenceGuidedCaptioningModel"):
+        self._o = owner
+        self.hidden_size = owner.arch.gpt.hidden
+        self.vocab_size = owner.arch.dec_vocab
+        self.vision_feature_dim = owner.projection_dim
+        self.engine = CaptionDecoderEngine(owner.store, owner.arch, owner.ws, "pol")
+
+    def forward(self, vision_features: torch.Tensor, input_ids: Optional[torch.Tensor] = None,
+                attention_mask: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                use_cache: bool = False, return_dict: bool = True) -> Dict[str, torch.Tensor]:
+        if input_ids is None:
+            raise NotImplementedError("prefix-only decoding (generation) is outside the training hot path")
+        dev = self._o.device
+        if attention_mask is None:
+            attention_mask = torch.ones_like(input_ids)
+        sb = make_seq_batch(input_ids, attention_mask, dev)
+        logits = self.engine.logits(vision_features.to(dev, F32).contiguous(), sb)
+        loss = None
+        if labels is not None:  # HF ForCausalLMLoss: mean CE over all shifted positions (modeling_gpt2.py:700-716)
+            B, S, V = logits.shape
+            full = make_seq_batch(labels, torch.ones_like(labels), dev)
+            tok = torch.empty(full.n_rows, dtype=F32, device=dev)
+            hip.logits_logprob(logits, V, V, full.row_map, full.targets, full.n_rows, tok)
+            loss = -tok.mean()
+        return {"logits": logits, "loss": loss}
+
+    __call__ = forward
+
+
+class PreferenceGuidedCaptioningModel:
+    """Drop-in for reference ``PreferenceGuidedCaptioningModel`` (model.py:681-853) on MI355X."""
+
+    def __init__(self, vision_model: str = "openai/clip-vit-base-patch32", text_model: str = "microsoft/DialoGPT-medium",
+                 projection_dim: int = 512, temperature: float = 0.07, dropout: float = 0.1,
+                 freeze_vision_backbone: bool = False, freeze_text_backbone: bool = False,
+                 lora_config: Optional[Dict[str, Any]] = None, *, device=None, seed: int = 0,
+                 arch: Optional[ModelArch] = None) -> None:
+        if lora_config:
+            raise NotImplementedError("LoRA adapters are disabled in every shipped reference config and not supported")
+        if not freeze_vision_backbone:
+            logger.warning("freeze_vision_backbone=False requested: the MI355X path keeps the CLIP tower frozen "
+                           "(forward-only kernels), as configs/default.yaml does")
+        self.projection_dim = projection_dim
+        self.temperature = temperature
+        self.dropout = dropout
+        self.device = torch.device(device) if device is not None else _default_device()
+        self.arch = arch if arch is not None else make_arch(vision_model, text_model, projection_dim)
+        frozen = ["vit"] + (["text_tower"] if freeze_text_backbone else [])
+        self.store = ParamStore(self.arch, self.device, seed=seed, frozen=frozen)
+        for seg in self.store.segments.values():
+            seg.ensure_bf16()
+            if seg.trainable:
+                seg.ensure_train_state()
+        hip.load()
+        self.ws = Workspace(self.device)
+        self.vision_encoder = VisionEncoder(self)
+        self.text_encoder = TextEncoder(self)
+        self.caption_decoder = CaptionDecoder(self)
+        self.training = True
+        self.logger = logger
+
+    # -- nn.Module-like conveniences ---------------------------------------------------------------
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, *a, **k):
+        return self
+
+    def parameters(self):
+        return [seg.w(n) for seg in self.store.segments.values() for n in seg.index]
+
+    def named_parameters(self):
+        return [(n, seg.w(n)) for seg in self.store.segments.values() for n in seg.index]
+
+    def state_dict(self):
+        return self.store.state_dict(aliases=True)
+
+    def load_state_dict(self, sd, strict: bool = False):
+        return self.store.load_state_dict(sd, strict=strict)
+
+    def sync_bf16(self) -> None:
+        """Refresh the bf16 mirrors after the f32 masters were edited outside the optimiser."""
+        for seg in self.store.segments.values():
+            seg.ensure_bf16()
+
+    # -- forward -----------------------------------------------------------------------------------
+    def forward(self, images: torch.Tensor, caption_ids: Optional[torch.Tensor] = None,
+                caption_mask: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
+                mode: str = "contrastive") -> Dict[str, torch.Tensor]:
+        outputs: Dict[str, torch.Tensor] = {}
+        vision_outputs = self.vision_encoder(images)
+        image_embeddings = vision_outputs["embeddings"]
+        B, P = image_embeddings.shape
+        if mode in ("contrastive", "dual") and caption_ids is not None:
+            text_outputs = self.text_encoder(caption_ids, caption_mask)
+            img_n = torch.empty(B, P, dtype=F32, device=self.device)
+            txt_n = torch.empty(B, P, dtype=F32, device=self.device)
+            hip.l2norm_fwd(image_embeddings, B, P, img_n)
+            hip.l2norm_fwd(text_outputs["embeddings"], B, P, txt_n)
+            outputs.update({"image_embeddings": img_n, "text_embeddings": txt_n,
+                            "vision_features": vision_outputs["features"], "text_features": text_outputs["features"]})
+        if mode in ("generation", "dual"):
+            dec = self.caption_decoder(vision_features=image_embeddings, input_ids=caption_ids,
+                                       attention_mask=caption_mask, labels=labels, return_dict=True)
+            outputs.update({"logits": dec["logits"],
+                            "generation_loss": dec["loss"] if dec["loss"] is not None
+                            else torch.tensor(0.0, device=self.device)})
+        return outputs
+
+    __call__ = forward
+
+    def sequence_logprobs(self, images: torch.Tensor, caption_ids: torch.Tensor, caption_mask: torch.Tensor,
+                          reduce: str = "mean") -> torch.Tensor:
+        """Fast entry: per-sequence log-prob without materialising [B,S,V] logits."""
+        emb = self.vision_encoder(images)["embeddings"]
+        sb = make_seq_batch(caption_ids, caption_mask, self.device)
+        return self.caption_decoder.engine.sequence_logprobs(emb, sb, reduce, save=False).clone()
+
+    def compute_similarity(self, images, captions, caption_mask) -> torch.Tensor:
+        out = self(images=images, caption_ids=captions, caption_mask=caption_mask, mode="contrastive")
+        return out["image_embeddings"] @ out["text_embeddings"].t() / self.temperature
+
+    def generate_captions(self, *a, **k) -> List[str]:
+        raise NotImplementedError("caption generation is outside the training hot path (SURVEY 8f N4)")

@@ -26,15 +26,24 @@ from .arch import GptArch, ModelArch, VitArch
 ALIGN = 64  # elements; 256 B in fp32, 128 B in bf16
 
 
+def _round_up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
 @dataclass
 class Spec:
     name: str
     shape: Tuple[int, ...]
     init: str  # "normal:<std>" | "zeros" | "ones" | "uniform:<bound>"
+    pad_rows: int = 0  # allocate (and keep zero) this many extra rows after the tensor
 
     @property
     def numel(self) -> int:
         return int(math.prod(self.shape))
+
+    @property
+    def alloc(self) -> int:
+        return self.numel + self.pad_rows * int(math.prod(self.shape[1:]))
 
 
 def _ln(prefix: str, n: int) -> List[Spec]:
@@ -88,10 +97,15 @@ def head_specs(prefix: str, in_f: int, proj: int) -> List[Spec]:
             + _ln(prefix + ".4", proj))
 
 
-def gpt2_specs(prefix: str, a: GptArch, vocab: int) -> List[Spec]:
+VOCAB_TILE = 128  # the tied LM head contracts over the vocabulary in 128-row GEMM tiles
+
+
+def gpt2_specs(prefix: str, a: GptArch, vocab: int, pad_vocab: bool = False) -> List[Spec]:
     """HF ``GPT2Model`` parameters (modeling_gpt2.py: attention :84-110, MLP :229-243,
-    block :246-262, model :486-500)."""
-    s: List[Spec] = [Spec(prefix + ".wte.weight", (vocab, a.hidden), "normal:0.02"),
+    block :246-262, model :486-500).  With ``pad_vocab`` the embedding table is followed by
+    zero rows up to a multiple of 128 so the LM-head dgrad GEMM (K = vocab) reads zeros."""
+    pad = (_round_up(vocab, VOCAB_TILE) - vocab) if pad_vocab else 0
+    s: List[Spec] = [Spec(prefix + ".wte.weight", (vocab, a.hidden), "normal:0.02", pad_rows=pad),
                      Spec(prefix + ".wpe.weight", (a.n_pos, a.hidden), "normal:0.02")]
     proj_std = 0.02 / math.sqrt(2 * a.layers)
     for i in range(a.layers):
@@ -127,13 +141,9 @@ def model_specs(a: ModelArch) -> "OrderedDict[str, List[Spec]]":
     segs["vision_head"] = head_specs("vision_encoder.projection", a.vit.hidden, a.proj_dim)
     segs["text_tower"] = gpt2_specs("text_encoder.text_model", a.gpt, a.text_vocab)
     segs["text_head"] = head_specs("text_encoder.projection", a.gpt.hidden, a.proj_dim)
-    segs["decoder"] = (gpt2_specs("caption_decoder.lm_model.transformer", a.gpt, a.dec_vocab)
+    segs["decoder"] = (gpt2_specs("caption_decoder.lm_model.transformer", a.gpt, a.dec_vocab, pad_vocab=True)
                        + decoder_extra_specs("caption_decoder", a))
     return segs
-
-
-def _round_up(n: int, m: int) -> int:
-    return (n + m - 1) // m * m
 
 
 class Segment:
@@ -149,7 +159,7 @@ class Segment:
             if sp.name in self.index:
                 raise ValueError(f"duplicate parameter {sp.name}")
             self.index[sp.name] = (off, sp.shape)
-            off += _round_up(sp.numel, ALIGN)
+            off += _round_up(sp.alloc, ALIGN)
         self.numel = off
         self.device = device
         self.fp32 = torch.zeros(off, dtype=torch.float32, device=device)
@@ -175,6 +185,13 @@ class Segment:
         if self.grad is None:
             raise RuntimeError(f"segment {self.name}: no gradient buffer (frozen?)")
         return self._view(self.grad, name)
+
+    def padded(self, flat: torch.Tensor, name: str) -> torch.Tensor:
+        """View including the zero pad rows (``[rows + pad_rows, cols]``)."""
+        off, shape = self.index[name]
+        sp = next(s for s in self.specs if s.name == name)
+        rows = shape[0] + sp.pad_rows
+        return flat[off:off + rows * int(math.prod(shape[1:]))].view((rows,) + tuple(shape[1:]))
 
     def ensure_bf16(self) -> None:
         if self.bf16 is None:

@@ -1,0 +1,230 @@
+"""End-to-end parity of the HIP path (through the model surface and the step engines).
+
+* tiny geometry: against the REFERENCE's own outputs/gradients (tests/golden/tiny_e2e.npz, produced
+  by oracle/make_golden.py from the imported reference) - same seeded weights, same batch.
+* config-2 geometry (ViT-B/32 + GPT-2-M, S=128): against the oracle restatement run on the host.
+
+Tolerances (SURVEY 8d, bf16 MFMA operands / f32 accumulate): per-sequence mean log-prob |d| <= 2e-2,
+loss |d| <= 5e-3, gradient cosine >= 0.99; gather indices bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def cos(a, b):
+    a, b = a.double().flatten().cpu(), torch.as_tensor(b).double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def tiny(golden):
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    g = golden("tiny_e2e")
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=tiny_arch(), seed=int(g["seed"]),
+                                            device="cuda:0")
+    for seg in model.store.segments.values():
+        chk = g[f"chk_{seg.name}"]
+        assert abs(float(seg.fp32.double().sum()) - chk[0]) <= 1e-5 * max(1.0, abs(chk[0]))
+    return g, model
+
+
+def dpo_step(model, reference_free, ref=None):
+    from pgca_amd.steps import DPOStep
+    return DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                   model.caption_decoder.engine, beta=0.1, reference_free=reference_free, ref=ref)
+
+
+def batch2(g, dev):
+    from pgca_amd.steps import DPOStep
+    b = {"image": T(g["images"]), "preferred_ids": T(g["ids_w"]), "rejected_ids": T(g["ids_l"]),
+         "preferred_mask": T(g["mask_w"]), "rejected_mask": T(g["mask_l"])}
+    return DPOStep.prepare(b, dev)
+
+
+def test_gather_indices_bit_exact(tiny):
+    g, model = tiny
+    p = batch2(g, model.device)
+    sb = p["seq"]
+    ids = np.concatenate([g["ids_w"], g["ids_l"]])
+    mask = np.concatenate([g["mask_w"], g["mask_l"]])
+    keep = mask[:, 1:] != 0
+    assert sb.targets.dtype == torch.int64
+    assert np.array_equal(sb.targets.cpu().numpy(), ids[:, 1:][keep])          # == labels[:, 1:] where scored
+    bi, ti = np.nonzero(keep)
+    assert np.array_equal(sb.row_map.cpu().numpy(), (bi * ids.shape[1] + ti).astype(np.int32))
+    assert np.array_equal(sb.counts.cpu().numpy(), keep.sum(1).astype(np.int32))
+
+
+def test_tiny_forward_surface_matches_reference(tiny):
+    g, model = tiny
+    img, iw, mw = T(g["images"]), T(g["ids_w"]), T(g["mask_w"])
+    out = model(images=img, caption_ids=iw, caption_mask=mw, mode="contrastive")
+    assert set(out) == {"image_embeddings", "text_embeddings", "vision_features", "text_features"}
+    np.testing.assert_allclose(out["image_embeddings"].cpu().numpy(), g["s1_image_embeddings"], atol=1.5e-2)
+    np.testing.assert_allclose(out["text_embeddings"].cpu().numpy(), g["s1_text_embeddings"], atol=1.5e-2)
+    np.testing.assert_allclose(out["vision_features"].cpu().numpy(), g["s1_vision_features"], atol=6e-2)
+    gen = model(images=img, caption_ids=iw, caption_mask=mw, labels=iw, mode="generation")
+    assert set(gen) == {"logits", "generation_loss"}
+    valid = g["mask_w"].astype(bool)
+    np.testing.assert_allclose(gen["logits"].cpu().numpy()[valid], g["s2_logits_w"][valid], atol=5e-2)
+    lp = model.sequence_logprobs(img, iw, mw, reduce="sum")
+    np.testing.assert_allclose(lp.cpu().numpy(), g["s2_seq_sum_w"], atol=2e-2 * 16)
+
+
+def test_tiny_input_validation(tiny):
+    _, model = tiny
+    with pytest.raises(ValueError, match="4D tensor"):
+        model.vision_encoder(torch.zeros(3, 64, 64))
+    with pytest.raises(ValueError, match="3 channels"):
+        model.vision_encoder(torch.zeros(1, 1, 64, 64))
+    with pytest.raises(ValueError, match="doesn't match"):
+        model.text_encoder(torch.zeros(2, 8, dtype=torch.long), torch.ones(2, 9, dtype=torch.long))
+
+
+def test_tiny_stage2_two_forward_matches_reference(tiny):
+    g, model = tiny
+    step = dpo_step(model, reference_free=True)
+    p = batch2(g, model.device)
+    for seg in model.store.trainable_segments():
+        seg.grad.zero_()
+    loss = step.loss_and_grads(p["image"], p["seq"])
+    assert abs(float(loss) - float(g["s2_pref_loss"])) <= 5e-3
+    for k in g.files:
+        if k.startswith("s2_grad::"):
+            name = k[len("s2_grad::"):]
+            c = cos(model.store.g(name), g[k])
+            if np.abs(g[k]).max() == 0:
+                assert float(model.store.g(name).abs().max()) == 0.0, name
+            else:
+                assert c >= 0.99, f"{name}: cosine {c}"
+    assert cos(model.store.g("caption_decoder.lm_model.transformer.wte.weight"), g["s2_grad_wte"]) >= 0.99
+    # q/k rows of the collapsed cross-attention receive exactly zero (not missing) gradient
+    H = model.arch.gpt.hidden
+    gi = model.store.g("caption_decoder.cross_attention.in_proj_weight")
+    assert float(gi[:2 * H].abs().max()) == 0.0 and float(gi[2 * H:].abs().max()) > 0
+    # nothing reaches the text tower in Stage 2
+    assert float(model.store.segments["text_tower"].grad.abs().max()) == 0.0
+
+
+def test_tiny_stage2_four_forward_dpo_matches_reference(tiny):
+    from pgca_amd.steps import ReferencePolicy
+    g, model = tiny
+    ref = ReferencePolicy(model.store, model.ws)
+    seg = ref.store.segments["decoder"]
+    for name in seg.index:  # the fixture's reference policy: snapshot with mlp.c_proj scaled by 0.9
+        if ".h." in name and name.endswith("mlp.c_proj.weight"):
+            seg.w(name).mul_(0.9)
+    seg.ensure_bf16()
+    step = dpo_step(model, reference_free=False, ref=ref)
+    p = batch2(g, model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss = step.loss_and_grads(p["image"], p["seq"])
+    B = 4
+    pol = step.dec.ws.bufs["pol.seq_lp"][:2 * B].cpu().numpy()
+    np.testing.assert_allclose(pol[:B], g["s2_pol_w"], atol=2e-2 * 16)   # length-sum: 2e-2 per token
+    assert abs(float(loss) - float(g["s2_dpo_loss"])) <= 5e-3
+    for k in g.files:
+        if k.startswith("s2dpo_grad::"):
+            name = k[len("s2dpo_grad::"):]
+            assert cos(model.store.g(name), g[k]) >= 0.99, name
+    assert cos(model.store.g("caption_decoder.lm_model.transformer.wte.weight"), g["s2dpo_grad_wte"]) >= 0.99
+    import json
+    met = step.metrics.cpu().numpy()
+    refm = json.loads(str(g["s2_dpo_metrics"]))
+    assert abs(met[0] - refm["reward_margin"]) <= 0.3 and abs(met[2] - refm["policy_chosen_logprob"]) <= 0.3
+
+
+def test_tiny_stage1_matches_reference(tiny):
+    from pgca_amd.steps import ContrastiveStep
+    g, model = tiny
+    step = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                           model.text_encoder.engine, temperature=0.5)
+    p = ContrastiveStep.prepare({"image": T(g["images"]), "caption_ids": T(g["ids_w"]), "caption_mask": T(g["mask_w"])},
+                                model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss = step.loss_and_grads(p["image"], p["ids"], p["mask"])
+    assert abs(float(loss) - float(g["s1_loss"])) <= 5e-3
+    for k in g.files:
+        if k.startswith("s1_grad::"):
+            name = k[len("s1_grad::"):]
+            assert cos(model.store.g(name), g[k]) >= 0.99, name
+    assert cos(model.store.g("text_encoder.text_model.wte.weight")[:64], g["s1_grad_wte_rows"]) >= 0.99
+    assert float(model.store.segments["decoder"].grad.abs().max()) == 0.0
+
+
+def test_optimizer_step_changes_only_trainable_segments(tiny):
+    from pgca_amd.steps import FusedOptimizer
+    g, model = tiny
+    step = dpo_step(model, reference_free=True)
+    p = batch2(g, model.device)
+    segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
+    opt = FusedOptimizer(segs, lr=1e-3, max_grad_norm=1.0, warmup_steps=0, total_steps=10)
+    before = {n: s.fp32.clone() for n, s in model.store.segments.items()}
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        losses.append(float(step.loss_and_grads(p["image"], p["seq"])))
+        opt.step()
+    st = opt.state()
+    assert st["finite"] and st["step"] == 3 and st["clip"] <= 1.0
+    assert losses[-1] < losses[0]                       # the same batch three times: the loss must fall
+    assert not torch.equal(model.store.segments["decoder"].fp32, before["decoder"])
+    assert torch.equal(model.store.segments["vit"].fp32, before["vit"])
+    assert torch.equal(model.store.segments["text_tower"].fp32, before["text_tower"])
+    assert torch.equal(model.store.segments["decoder"].bf16, model.store.segments["decoder"].fp32.bfloat16())
+    for n, s in model.store.segments.items():            # restore for any later test
+        s.fp32.copy_(before[n])
+        s.ensure_bf16()
+
+
+def test_config2_geometry_against_oracle():
+    """ViT-B/32 + GPT-2-M widths at S = 128 with 2 layers each (full depth is the bench's job):
+    fused log-probs, DPO loss and gradients vs the CPU restatement on identical weights/batch."""
+    from pgca_amd.arch import make_arch, with_layers
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    from pgca_amd.steps import DPOStep
+    arch = with_layers(make_arch("openai/clip-vit-base-patch32", "gpt2-medium", 512), 2, 2)
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=arch, seed=7, device="cuda:0")
+    gen = torch.Generator().manual_seed(1234)
+    B, S = 2, 128
+    img = torch.randn(B, 3, 224, 224, generator=gen)
+    ids = torch.randint(0, 50257, (2 * B, S), generator=gen)
+    lens = torch.tensor([128, 40, 77, 16])
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    ids = torch.where(mask.bool(), ids, torch.full_like(ids, 50257))
+    batch = {"image": img, "preferred_ids": ids[:B], "rejected_ids": ids[B:], "preferred_mask": mask[:B],
+             "rejected_mask": mask[B:]}
+    step = dpo_step(model, reference_free=True)
+    p = DPOStep.prepare(batch, model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss = step.loss_and_grads(p["image"], p["seq"])
+    pol = model.ws.bufs["pol.seq_lp"][:2 * B].cpu()
+    # oracle on the host
+    sd = {k: v.detach().cpu().clone().requires_grad_(k.startswith(("caption_decoder", "vision_encoder.projection")))
+          for k, v in model.store.state_dict(aliases=False).items()}
+    lw = R.model_forward(sd, img, ids[:B], mask[:B], "generation", arch.vit.heads, arch.vit.patch, arch.gpt.heads)["logits"]
+    ll = R.model_forward(sd, img, ids[B:], mask[B:], "generation", arch.vit.heads, arch.vit.patch, arch.gpt.heads)["logits"]
+    ref_w, ref_l = R.sequence_logprob_mean(lw, ids[:B], mask[:B]), R.sequence_logprob_mean(ll, ids[B:], mask[B:])
+    ref_loss = R.preference_loss(lw, ll, ids[:B], ids[B:], mask[:B], mask[B:], 0.1)
+    ref_loss.backward()
+    assert float((pol[:B] - ref_w.detach()).abs().max()) <= 2e-2
+    assert float((pol[B:] - ref_l.detach()).abs().max()) <= 2e-2
+    assert abs(float(loss) - float(ref_loss)) <= 5e-3
+    dec = "caption_decoder.lm_model.transformer."
+    for name in (dec + "h.1.attn.c_attn.weight", dec + "h.0.mlp.c_fc.weight", dec + "h.1.mlp.c_proj.weight",
+                 dec + "h.0.attn.c_proj.bias", dec + "h.0.ln_1.weight", dec + "ln_f.weight", dec + "wpe.weight",
+                 dec + "wte.weight", "caption_decoder.vision_projection.0.weight",
+                 "caption_decoder.cross_attention.out_proj.weight", "caption_decoder.attention_norm.weight",
+                 "vision_encoder.projection.0.weight", "vision_encoder.projection.4.weight"):
+        c = cos(model.store.g(name), sd[name].grad)
+        assert c >= 0.99, f"{name}: cosine {c}"
