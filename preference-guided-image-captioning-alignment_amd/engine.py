@@ -134,6 +134,11 @@ class GptTrunk:
                 ("bfc", ".mlp.c_fc.bias"), ("wpr", ".mlp.c_proj.weight"), ("bpr", ".mlp.c_proj.bias"))})
         self.lnf_w, self.lnf_b = _P(seg, prefix + ".ln_f.weight"), _P(seg, prefix + ".ln_f.bias")
         self.saved: Optional[dict] = None
+        # flat-buffer range [start, end) of each layer's parameters (for bucketed gradient all-reduce)
+        starts = [seg.index[f"{prefix}.h.{i}.ln_1.weight"][0] for i in range(arch.layers)]
+        starts.append(seg.index[prefix + ".ln_f.weight"][0])
+        self.layer_ranges = [(starts[i], starts[i + 1]) for i in range(arch.layers)]
+        self.grad_hook = None  # callable(layer_index) fired when a layer's gradients are complete
 
     def _buf(self, name, shape, dtype, zero=False):
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
@@ -219,6 +224,8 @@ class GptTrunk:
                               dx_bf16=g3_bf, part=part)
             _ln_param_grads(part, nb, H, P["ln1w"].g, P["ln1b"].g)
             g, g_bf = g3, g3_bf
+            if self.grad_hook is not None:
+                self.grad_hook(li)
         return g
 
 
@@ -454,7 +461,10 @@ class CaptionDecoderEngine:
         ws = self.ws
         rs = self._buf("row_scale", (Mc,), F32)
         hip.row_scale(dseq, sb.seq_of_row, sb.counts, Mc, 1 if s["reduce"] == "mean" else 0, rs)
-        # LM head: dlogits = g * (softmax - onehot), recomputed tile by tile in row chunks
+        # d tok_lp / d logits = onehot - softmax; the DLOGITS epilogue computes the cross-entropy form
+        # row_scale * (softmax - onehot), so it is fed -dLoss/dtok_lp
+        rs.neg_()
+        # LM head: dlogits recomputed tile by tile in row chunks
         dhf = self._buf("dhf", (Mc, H), BF16)
         ck = min(self.LM_CHUNK, Mc)
         dl = self._buf("dlogits", (ck, self.Vp), BF16)

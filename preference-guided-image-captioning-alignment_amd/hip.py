@@ -137,7 +137,19 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
     a.targets, a.stat_max, a.stat_sum, a.stat_ld = _p(targets), _p(stat_max), _p(stat_sum), stat_ld
     a.target_val, a.row_lse, a.row_scale = _p(target_val), _p(row_lse), _p(row_scale)
     a.out_cols = out_cols
+    probe = gemm_probe
+    if probe is not None and probe.want(layout, epilogue, M, N, K):
+        # HIP events on the launch stream bracket this one kernel (bench.py roofline measurement)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _check(load().pgca_gemm_bf16(C.byref(a), _stream()), "pgca_gemm_bf16")
+        e1.record()
+        probe.add(e0, e1, 2.0 * M * N * K)
+        return
     _check(load().pgca_gemm_bf16(C.byref(a), _stream()), "pgca_gemm_bf16")
+
+
+gemm_probe = None  # optional object with want(layout, epilogue, M, N, K) / add(ev0, ev1, flops)
 
 
 def rowstats_combine(stat_max, stat_sum, stat_ld, nparts, target_val, M, lse=None, out_logprob=None):
