@@ -65,6 +65,20 @@ class GemmProbe:
         return {"launches": len(self.events), "avg_us": 1e3 * ms / len(self.events), "tflops": fl / (ms * 1e-3) / 1e12}
 
 
+def host_cores() -> int:
+    """Cores this process may actually use (cgroup/affinity share, capped at 16 = the 1-GPU box share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def log(msg: str) -> None:
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def cpu_baseline(model, arch, S, beta, pairs):
     """Oracle (CPU restatement, fp32) on the host cores: one 4-forward DPO step, fwd + bwd."""
     from oracle import restatement as R
@@ -129,6 +143,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B, S, beta = args.pairs_per_gpu, args.seq_len, 0.1
+    log(f"init: world={world} pairs/gpu={B} S={S}")
     arch = make_arch(args.vision_model, args.text_model, 512)
     model = PreferenceGuidedCaptioningModel(args.vision_model, args.text_model, 512, temperature=0.5,
                                             freeze_vision_backbone=True, device=dev, seed=42)
@@ -140,6 +155,7 @@ def main():
                          total_steps=100000, sched_stride=dp.world)
     reducer = OverlappedTrunkReducer(dp, model.caption_decoder.engine.trunk, group=4)
     reducer.arm()
+    log(f"model + optimizer ready ({model.store.num_params() / 1e6:.1f} M params)")
 
     nbatch = 4  # distinct resident batches, cycled
     batches = [DPOStep.prepare(synthetic_batch(B, S, arch.gpt.base_vocab, arch.gpt.base_vocab,
@@ -155,8 +171,11 @@ def main():
         reducer.finish(other_segments=[segs[0]])
         opt.step(grad_scale=1.0 / dp.world)
 
+    log("batches resident; warm-up")
     for i in range(args.warmup):
         one_step(i)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done, loss={float(step.loss):.5f}")
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -170,6 +189,7 @@ def main():
     dt = time.perf_counter() - t0
     probe.enabled = False
     dt = dp.all_reduce_max_scalar(dt, dev)
+    log(f"timed region: {args.steps} steps in {dt:.3f} s -> {B * dp.world * args.steps / dt:.1f} pairs/s")
     loss_val = float(step.loss)
     st = opt.state()
 
@@ -207,6 +227,7 @@ def main():
                                "avg_launch_us": ps["avg_us"]}
         if dp.world == 1 and not args.no_cpu_baseline:
             hip.gemm_probe = None
+            log("cpu baseline (oracle on host cores) ...")
             res["cpu_baseline"] = cpu_baseline(model, arch, S, beta, args.cpu_pairs)
         print(json.dumps(res), flush=True)
     dp.barrier()

@@ -95,6 +95,193 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int wbase,
   }
 }
 
+// ---- epilogues ------------------------------------------------------------------------------------
+// Accumulator element acc[mi][ni][r] of wave (wm, wn) is C[m0 + wm*64 + mi*16 + (lane>>4)*4 + r]
+//                                                        [n0 + wn*64 + ni*16 + (lane&15)].
+__device__ __forceinline__ void epilogue_rowstats(const pgca_gemm_args& a, f32x4 (&acc)[4][4], int m0, int n0, int tn,
+                                                  int wm, int wn, int lane) {
+  const int rbase = m0 + wm * 64 + (lane >> 4) * 4;
+  const int cbase = n0 + wn * 64 + (lane & 15);
+  const int part = tn * 2 + wn;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + mi * 16 + r;
+      const long long tgt = (row < a.M && a.targets) ? a.targets[row] : -1;
+      float v0, v1, v2, v3;
+      {
+        float x[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int col = cbase + ni * 16;
+          float t = a.alpha * acc[mi][ni][r];
+          if (a.bias && col < a.N) t += a.bias[col];
+          if (col == tgt && a.target_val) a.target_val[row] = t;
+          x[ni] = col < a.N ? t : -INFINITY;
+        }
+        v0 = x[0]; v1 = x[1]; v2 = x[2]; v3 = x[3];
+      }
+      float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      float sm = 0.f;
+      if (mx > -INFINITY) sm = __expf(v0 - mx) + __expf(v1 - mx) + __expf(v2 - mx) + __expf(v3 - mx);
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+      if ((lane & 15) == 0 && row < a.M) {
+        a.stat_max[(size_t)row * a.stat_ld + part] = mx;
+        a.stat_sum[(size_t)row * a.stat_ld + part] = sm;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Everything that happens to 8 consecutive output columns of one row.  `nv` = number of valid columns (1..8);
+// the 16-byte vector paths are taken when nv == 8 and the row start is 16-B aligned, else element-wise.
+template <int EPI>
+__device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int col, float (&v)[8], int nv, float lse,
+                                        float rscale, long long tgt) {
+  const bool full = nv == 8;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] *= a.alpha;
+  if (a.bias) {
+    const float* bp = a.bias + col;
+    if (full && al16(bp)) {
+      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < nv && col + j < a.N) v[j] += bp[j];
+    }
+  }
+  if (EPI == PGCA_EPI_GELU_NEW || EPI == PGCA_EPI_QUICK_GELU) {
+    if (a.aux_out) {
+      bf16_t* p = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col;
+      if (full && al16(p)) {
+        bf16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = f2bf(v[j]);
+        *reinterpret_cast<bf16x8*>(p) = t;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = EPI == PGCA_EPI_GELU_NEW ? gelu_new(v[j]) : quick_gelu(v[j]);
+  } else if (EPI == PGCA_EPI_RELU) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (EPI == PGCA_EPI_TANH) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fast_tanh(v[j]);
+  } else if (EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH) {
+    const bf16_t* p = reinterpret_cast<const bf16_t*>(a.aux_in) + (size_t)row * a.ld_aux + col;
+    float x[8];
+    if (full && al16(p)) {
+      const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = bf2f(t[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = j < nv ? bf2f(p[j]) : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (EPI == PGCA_EPI_DGELU_NEW) v[j] *= dgelu_new(x[j]);
+      else if (EPI == PGCA_EPI_DRELU) v[j] = x[j] > 0.f ? v[j] : 0.f;
+      else v[j] *= 1.f - x[j] * x[j];
+    }
+  } else if (EPI == PGCA_EPI_DLOGITS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = (col + j) < a.N ? rscale * (__expf(v[j] - lse) - ((col + j) == tgt ? 1.f : 0.f)) : 0.f;
+  }
+  if (a.residual) {
+    const float* p = a.residual + (size_t)row * a.ld_res + col;
+    if (full && al16(p)) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p), b1 = *reinterpret_cast<const float4*>(p + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < nv) v[j] += p[j];
+    }
+  }
+  if (a.out_f32) {
+    float* p = a.out_f32 + (size_t)row * a.ld_out_f32 + col;
+    if (full && al16(p)) {
+      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+      if (a.accumulate) {
+        const float4 c0 = *reinterpret_cast<const float4*>(p), c1 = *reinterpret_cast<const float4*>(p + 4);
+        o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
+      }
+      *reinterpret_cast<float4*>(p) = o0;
+      *reinterpret_cast<float4*>(p + 4) = o1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < nv) p[j] = a.accumulate ? p[j] + v[j] : v[j];
+    }
+  }
+  if (a.out_bf16) {
+    bf16_t* p = reinterpret_cast<bf16_t*>(a.out_bf16) + (size_t)row * a.ld_out_bf16 + col;
+    if (full && al16(p)) {
+      bf16x8 t;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t[j] = f2bf(v[j]);
+      *reinterpret_cast<bf16x8*>(p) = t;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
+    }
+  }
+}
+
+// The wave's 64x64 accumulator tile goes through LDS in two 32-row halves (row stride 68 floats: conflict-free
+// b32 writes in the MFMA layout, b128 reads of 8 consecutive columns), so every global access of the epilogue
+// (bias, saved activations, residual stream, outputs) is a 16-byte vector op on 128..256 contiguous bytes per row.
+template <int EPI>
+__device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int m0,
+                                               int n0, int wm, int wn, int lane, int wave) {
+  constexpr int LDC = 68;
+  float* cbuf = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+  const int ncols = EPI == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cbuf[(mh * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = acc[half * 2 + mh][ni][r];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int lr = it * 8 + (lane >> 3);
+      const int row = m0 + wm * 64 + half * 32 + lr;
+      const int col = n0 + wn * 64 + (lane & 7) * 8;
+      const float4 c0 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + (lane & 7) * 8);
+      const float4 c1 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + (lane & 7) * 8 + 4);
+      if (row < a.M && col < ncols) {
+        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float lse = 0.f, rscale = 0.f;
+        long long tgt = -1;
+        if (EPI == PGCA_EPI_DLOGITS) {
+          lse = a.row_lse[row];
+          rscale = a.row_scale[row];
+          tgt = a.targets[row];
+        }
+        const int nv = ncols - col < 8 ? ncols - col : 8;
+        finish8<EPI>(a, row, col, v, nv, lse, rscale, tgt);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <int LA, int LB>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const pgca_gemm_args a, int ntm, int ntn) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2][2][TILE_BYTES];
@@ -170,101 +357,18 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pgca_gemm_args a, in
   }
 
   // ------------------------------------------------------------------------------- epilogue
-  const int rbase = m0 + wm * 64 + (lane >> 4) * 4;  // + mi*16 + r
-  const int cbase = n0 + wn * 64 + (lane & 15);      // + ni*16
-  const int epi = a.epilogue;
-
-  if (epi == PGCA_EPI_ROWSTATS) {
-    const int part = tn * 2 + wn;
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rbase + mi * 16 + r;
-        const long long tgt = (row < a.M && a.targets) ? a.targets[row] : -1;
-        float v[4];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int col = cbase + ni * 16;
-          float x = a.alpha * acc[mi][ni][r];
-          if (a.bias && col < a.N) x += a.bias[col];
-          v[ni] = col < a.N ? x : -INFINITY;
-          mx = fmaxf(mx, v[ni]);
-          if (col == tgt && a.target_val) a.target_val[row] = x;
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sm = 0.f;
-        if (mx > -INFINITY) {
-#pragma unroll
-          for (int ni = 0; ni < 4; ++ni) sm += __expf(v[ni] - mx);
-        }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
-        if ((lane & 15) == 0 && row < a.M) {
-          a.stat_max[(size_t)row * a.stat_ld + part] = mx;
-          a.stat_sum[(size_t)row * a.stat_ld + part] = sm;
-        }
-      }
-    }
-    return;
-  }
-
-  bf16_t* ob = reinterpret_cast<bf16_t*>(a.out_bf16);
-  const bf16_t* auxi = reinterpret_cast<const bf16_t*>(a.aux_in);
-  bf16_t* auxo = reinterpret_cast<bf16_t*>(a.aux_out);
-  const int ncol_store = (epi == PGCA_EPI_DLOGITS) ? a.out_cols : a.N;
-
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rbase + mi * 16 + r;
-      if (row >= a.M) continue;
-      float lse = 0.f, rscale = 0.f;
-      long long tgt = -1;
-      if (epi == PGCA_EPI_DLOGITS) {
-        lse = a.row_lse[row];
-        rscale = a.row_scale[row];
-        tgt = a.targets[row];
-      }
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int col = cbase + ni * 16;
-        if (col >= ncol_store) continue;
-        float v = a.alpha * acc[mi][ni][r];
-        if (a.bias && col < a.N) v += a.bias[col];
-        switch (epi) {
-          case PGCA_EPI_GELU_NEW:
-            if (auxo) auxo[(size_t)row * a.ld_aux + col] = f2bf(v);
-            v = gelu_new(v);
-            break;
-          case PGCA_EPI_QUICK_GELU:
-            if (auxo) auxo[(size_t)row * a.ld_aux + col] = f2bf(v);
-            v = quick_gelu(v);
-            break;
-          case PGCA_EPI_RELU: v = fmaxf(v, 0.f); break;
-          case PGCA_EPI_TANH: v = fast_tanh(v); break;
-          case PGCA_EPI_DGELU_NEW: v *= dgelu_new(bf2f(auxi[(size_t)row * a.ld_aux + col])); break;
-          case PGCA_EPI_DRELU: v = bf2f(auxi[(size_t)row * a.ld_aux + col]) > 0.f ? v : 0.f; break;
-          case PGCA_EPI_DTANH: {
-            const float y = bf2f(auxi[(size_t)row * a.ld_aux + col]);
-            v *= 1.f - y * y;
-          } break;
-          case PGCA_EPI_DLOGITS:
-            v = col < a.N ? rscale * (__expf(v - lse) - (col == tgt ? 1.f : 0.f)) : 0.f;
-            break;
-          default: break;
-        }
-        if (a.residual) v += a.residual[(size_t)row * a.ld_res + col];
-        if (a.out_f32) {
-          float* p = a.out_f32 + (size_t)row * a.ld_out_f32 + col;
-          *p = a.accumulate ? (*p + v) : v;
-        }
-        if (ob) ob[(size_t)row * a.ld_out_bf16 + col] = f2bf(v);
-      }
-    }
+  unsigned char* sbase = &smem[0][0][0];
+  switch (a.epilogue) {
+    case PGCA_EPI_ROWSTATS: epilogue_rowstats(a, acc, m0, n0, tn, wm, wn, lane); break;
+    case PGCA_EPI_GELU_NEW: epilogue_store<PGCA_EPI_GELU_NEW>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_QUICK_GELU: epilogue_store<PGCA_EPI_QUICK_GELU>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_RELU: epilogue_store<PGCA_EPI_RELU>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_TANH: epilogue_store<PGCA_EPI_TANH>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_DGELU_NEW: epilogue_store<PGCA_EPI_DGELU_NEW>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_DRELU: epilogue_store<PGCA_EPI_DRELU>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_DTANH: epilogue_store<PGCA_EPI_DTANH>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    default: epilogue_store<PGCA_EPI_NONE>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
   }
 }
 

@@ -317,13 +317,26 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------ column sums
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts, int H, float* __restrict__ out,
-                                     int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+// out[c] (+)= sum_b part[b, c].  Block = 32 columns x 8 row slices: every load is 128 contiguous bytes,
+// each thread sums nparts/8 independent partials, the 8 slices meet in LDS.
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, int nparts, int H,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
   float s = 0.f;
-  for (int b = 0; b < nparts; ++b) s += part[(size_t)b * H + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < H) {
+#pragma unroll 4
+    for (int b = sl; b < nparts; b += 8) s += part[(size_t)b * H + c];
+  }
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl == 0 && c < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 // part[blockIdx.y, n] = sum over this block's rows of x[m, n]; 8 columns per thread.
@@ -392,7 +405,7 @@ extern "C" int pgca_layernorm_fwd(const float* x, const int32_t* row_map, int32_
 
 extern "C" int pgca_layernorm_bwd_blocks(int32_t M) {
   int b = (M + 3) / 4;
-  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+  return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
 
 extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
@@ -418,14 +431,14 @@ extern "C" int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, 
     set_error("pgca_colsum_finish: bad arguments");
     return PGCA_ERR_INVALID;
   }
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((H + 255) / 256), dim3(256), 0, (hipStream_t)stream, part, nparts, H,
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nparts, H,
                      out, accumulate);
   return check_launch("pgca_colsum_finish");
 }
 
 extern "C" int pgca_colsum_blocks(int32_t M) {
-  int b = (M + 63) / 64;
-  return b < 1 ? 1 : (b > 256 ? 256 : b);
+  int b = (M + 127) / 128;
+  return b < 1 ? 1 : (b > 128 ? 128 : b);
 }
 
 extern "C" int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, int32_t ld, float* part,
