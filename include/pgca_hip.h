@@ -113,11 +113,13 @@ int pgca_layernorm_fwd(const float* x, const int32_t* row_map, int32_t M, int32_
  * dx_out[row] = (add_to ? add_to[row] : 0) + dx   with row = row_map ? row_map[m] : m.
  * dx_bf16 (optional) receives the same value rounded to bf16 (operand of the next dgrad GEMM).
  * dgamma/dbeta partial sums go to part[2, nblk, H] (nblk returned by pgca_layernorm_bwd_blocks);
- * pgca_colsum_finish folds them into the gradient buffers. */
+ * pgca_colsum_finish folds them into the gradient buffers.  part_extra[2, nblk, H] (optional) receives the column
+ * sums of add_to and of dx_out - the bias gradients of the two GEMMs around this LayerNorm, for free. */
 int pgca_layernorm_bwd_blocks(int32_t M);
 int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
                        int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
-                       const float* add_to, float* dx_out, void* dx_bf16, float* part, void* stream);
+                       const float* add_to, float* dx_out, void* dx_bf16, float* part, float* part_extra,
+                       void* stream);
 /* out[h] (+)= sum_b part[b, h]; nparts rows of length H. */
 int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, float* out, int32_t accumulate, void* stream);
 

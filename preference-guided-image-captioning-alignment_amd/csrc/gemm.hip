@@ -294,7 +294,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pgca_gemm_args a, in
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int tm = bid % ntm, tn = bid / ntm;
+  // ... and inside that run tiles are visited in 8-row groups, N fastest within a group: the ~64 blocks an
+  // XCD holds at once cover an 8 x 8 patch of tiles, so each A and B panel is fetched into its L2 once per 8 uses.
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * ntn;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(GROUP_M, ntm - first_m);
+  const int in_group = bid - group * per_group;
+  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int t = threadIdx.x;

@@ -123,18 +123,21 @@ __device__ __forceinline__ void write_partials(float4 (&dg)[NV], float4 (&db)[NV
   }
 }
 
-template <int NV>
+template <int NV, bool EXTRA>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dyb, const float* __restrict__ dyf,
                                                      const float* __restrict__ x, const int* __restrict__ row_map,
                                                      int M, int H, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ add_to, float* __restrict__ dx_out,
-                                                     bf16_t* __restrict__ dx_bf, float* __restrict__ part) {
+                                                     bf16_t* __restrict__ dx_bf, float* __restrict__ part,
+                                                     float* __restrict__ part_extra) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
-  float4 dg[NV], db[NV], gm[NV];
+  float4 dg[NV], db[NV], gm[NV], sa[NV], sd[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) sa[j] = sd[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -182,13 +185,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         if (add_to) {
           const float4 a = *reinterpret_cast<const float4*>(add_to + row * H + c);
           d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+          if (EXTRA) { sa[j].x += a.x; sa[j].y += a.y; sa[j].z += a.z; sa[j].w += a.w; }
         }
+        if (EXTRA) { sd[j].x += d.x; sd[j].y += d.y; sd[j].z += d.z; sd[j].w += d.w; }
         *reinterpret_cast<float4*>(dx_out + row * H + c) = d;
         if (dx_bf) store_bf16x4(dx_bf + row * H + c, d);
       }
     }
   }
   if (part) write_partials<NV>(dg, db, H, part, gridDim.x, red);
+  if (EXTRA) {
+    // column sums of the two residual-stream gradients this pass touches anyway: sum(add_to) is the bias
+    // gradient of the GEMM that produced this block's output, sum(dx_out) that of the one feeding this LN's input
+    __syncthreads();
+    write_partials<NV>(sa, sd, H, part_extra, gridDim.x, red);
+  }
 }
 
 // ------------------------------------------------------------------------------------ embeddings
@@ -339,29 +350,46 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
   }
 }
 
-// part[blockIdx.y, n] = sum over this block's rows of x[m, n]; 8 columns per thread.
+// part[blockIdx.y, n] = sum over this block's rows of x[m, n].  Block = 32 column groups (8 columns = one 16-B
+// bf16 load) x 8 row lanes; a block covers 256 columns x rows_per_blk rows; row lanes meet in LDS.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ xb, const float* __restrict__ xf,
                                                      int M, int N, int ld, int rows_per_blk, float* __restrict__ part) {
-  const int c0 = (blockIdx.x * 256 + threadIdx.x) * 8;
-  if (c0 >= N) return;
+  __shared__ float red[8][32][9];
+  const int cg = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + cg) * 8;
   const int r0 = blockIdx.y * rows_per_blk;
   const int r1 = min(M, r0 + rows_per_blk);
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const bool full = c0 + 8 <= N;
-  for (int r = r0; r < r1; ++r) {
-    if (xb) {
-      if (full) {
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + (size_t)r * ld + c0);
+  if (c0 < N) {
+    const bool full = c0 + 8 <= N;
+    for (int r = r0 + ry; r < r1; r += 8) {
+      if (xb) {
+        if (full) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + (size_t)r * ld + c0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+          for (int i = 0; i < 8; ++i) acc[i] += (float)v[i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) if (c0 + i < N) acc[i] += (float)xb[(size_t)r * ld + c0 + i];
+        }
       } else {
-        for (int i = 0; i < 8 && c0 + i < N; ++i) acc[i] += (float)xb[(size_t)r * ld + c0 + i];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (c0 + i < N) acc[i] += xf[(size_t)r * ld + c0 + i];
       }
-    } else {
-      for (int i = 0; i < 8 && c0 + i < N; ++i) acc[i] += xf[(size_t)r * ld + c0 + i];
     }
   }
-  for (int i = 0; i < 8 && c0 + i < N; ++i) part[(size_t)blockIdx.y * N + c0 + i] = acc[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) red[ry][cg][i] = acc[i];
+  __syncthreads();
+  // 256 threads -> 256 columns of this block
+  const int col = threadIdx.x;
+  const int gcol = blockIdx.x * 256 + col;
+  if (gcol < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][col >> 3][col & 7];
+    part[(size_t)blockIdx.y * N + gcol] = s;
+  }
 }
 
 int nv_for(int H) { return (H + 255) / 256; }
@@ -405,14 +433,15 @@ extern "C" int pgca_layernorm_fwd(const float* x, const int32_t* row_map, int32_
 
 extern "C" int pgca_layernorm_bwd_blocks(int32_t M) {
   int b = (M + 3) / 4;
-  return b < 1 ? 1 : (b > 256 ? 256 : b);
+  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
 }
 
 extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
                                   int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
-                                  const float* add_to, float* dx_out, void* dx_bf16, float* part, void* stream) {
+                                  const float* add_to, float* dx_out, void* dx_bf16, float* part, float* part_extra,
+                                  void* stream) {
   if (check_h("pgca_layernorm_bwd", H)) return PGCA_ERR_INVALID;
-  if ((!dy_bf16) == (!dy_f32) || !x || !gamma || !mean || !rstd || !dx_out || M <= 0) {
+  if ((!dy_bf16) == (!dy_f32) || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || (part_extra && !part)) {
     set_error("pgca_layernorm_bwd: bad arguments");
     return PGCA_ERR_INVALID;
   }
@@ -420,8 +449,15 @@ extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, cons
   dim3 grid(pgca_layernorm_bwd_blocks(M)), block(256);
   const int nv = nv_for(H);
   const size_t lds = (size_t)2 * 4 * nv * 256 * sizeof(float);
-  DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32, x,
-                                     row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part));
+  if (part_extra) {
+    DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32,
+                                       x, row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part,
+                                       part_extra));
+  } else {
+    DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32,
+                                       x, row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part,
+                                       part_extra));
+  }
   return check_launch("pgca_layernorm_bwd");
 }
 
@@ -437,8 +473,8 @@ extern "C" int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, 
 }
 
 extern "C" int pgca_colsum_blocks(int32_t M) {
-  int b = (M + 127) / 128;
-  return b < 1 ? 1 : (b > 128 ? 128 : b);
+  int b = (M + 63) / 64;
+  return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
 
 extern "C" int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, int32_t ld, float* part,
@@ -449,7 +485,7 @@ extern "C" int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, in
   }
   const int nb = pgca_colsum_blocks(M);
   const int rows = (M + nb - 1) / nb;
-  dim3 grid((N + 2047) / 2048, nb), block(256);
+  dim3 grid((N + 255) / 256, nb), block(256);
   hipLaunchKernelGGL(colsum_kernel, grid, block, 0, (hipStream_t)stream, (const bf16_t*)x_bf16, x_f32, M, N, ld, rows,
                      part);
   return check_launch("pgca_colsum");

@@ -192,13 +192,13 @@ class GptTrunk:
         ws = self.ws
         nb = hip.layernorm_bwd_blocks(M)
         part = ws.get("ln_part", (2, nb, H), F32)
+        partx = ws.get("ln_partx", (2, nb, H), F32)
         for li in range(len(self.layers) - 1, -1, -1):
             P, s = self.layers[li], sv[li]
             # ---- MLP: h_out = hm + c_proj(gelu(c_fc(ln2(hm))))
             dpre = self._buf("dpre", (M, I), BF16)
             hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=s["pre"], out_bf16=dpre)
             hip.gemm(s["act"], g_bf, I, H, M, hip.TN, lda=I, ldb=H, out_f32=P["wpr"].g, accumulate=True)
-            _bias_grad(ws, M, H, H, P["bpr"].g, x_f32=g)
             dln = self._buf("dln", (M, H), BF16)
             hip.gemm(dpre, P["wfc"].b, M, H, I, hip.NT, out_bf16=dln)
             hip.gemm(s["ln2"], dpre, H, I, M, hip.TN, lda=H, ldb=I, out_f32=P["wfc"].g, accumulate=True)
@@ -206,13 +206,14 @@ class GptTrunk:
             g2 = self._buf("g_b" if (li & 1) else "g_a", (M, H), F32)
             g2_bf = self._buf("gbf_b" if (li & 1) else "gbf_a", (M, H), BF16)
             hip.layernorm_bwd(s["hm"], M, H, P["ln2w"].w, s["m2"], s["r2"], g2, dy_bf16=dln, add_to=g, dx_bf16=g2_bf,
-                              part=part)
+                              part=part, part_extra=partx)
             _ln_param_grads(part, nb, H, P["ln2w"].g, P["ln2b"].g)
+            # the same pass summed g (bias gradient of mlp.c_proj) and g2 (bias gradient of attn.c_proj)
+            _ln_param_grads(partx, nb, H, P["bpr"].g, P["bo"].g)
             # ---- attention: hm = hin + c_proj(attn(c_attn(ln1(hin))))
             datt = self._buf("datt", (M, H), BF16)
             hip.gemm(g2_bf, P["wo"].b, M, H, H, hip.NT, out_bf16=datt)
             hip.gemm(s["att"], g2_bf, H, H, M, hip.TN, lda=H, ldb=H, out_f32=P["wo"].g, accumulate=True)
-            _bias_grad(ws, M, H, H, P["bo"].g, x_f32=g2)
             dqkv = self._buf("dqkv", (M, 3 * H), BF16)
             hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], Bq, S, a.heads, True, dqkv)
             hip.gemm(dqkv, P["wqkv"].b, M, H, 3 * H, hip.NT, out_bf16=dln)

@@ -47,7 +47,7 @@ _SIGS = {
     "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_layernorm_bwd_blocks": [_i32],
-    "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pgca_colsum_finish": [_vp, _i32, _i32, _vp, _i32, _vp],
     "pgca_colsum_blocks": [_i32],
     "pgca_colsum": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -168,9 +168,10 @@ def layernorm_bwd_blocks(M: int) -> int:
 
 
 def layernorm_bwd(x, M, H, gamma, mean, rstd, dx_out, *, dy_bf16=None, dy_f32=None, row_map=None, add_to=None,
-                  dx_bf16=None, part=None):
+                  dx_bf16=None, part=None, part_extra=None):
     _check(load().pgca_layernorm_bwd(_p(dy_bf16), _p(dy_f32), _p(x), _p(row_map), M, H, _p(gamma), _p(mean),
-                                     _p(rstd), _p(add_to), _p(dx_out), _p(dx_bf16), _p(part), _stream()),
+                                     _p(rstd), _p(add_to), _p(dx_out), _p(dx_bf16), _p(part), _p(part_extra),
+                                     _stream()),
            "pgca_layernorm_bwd")
 
 
