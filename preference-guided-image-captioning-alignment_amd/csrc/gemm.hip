@@ -12,6 +12,8 @@
 // (XOR-swizzled, conflict-free for both fragment read kinds), double-buffered: the next
 // tile's global loads are issued before the current tile's MFMAs and written to the other
 // LDS buffer after them (one barrier per K tile).
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace pgca;
@@ -79,7 +81,7 @@ struct Stage {
 // ---- fragment readers ---------------------------------------------------------------------------
 // Returns the MFMA 16x16x32 operand fragment of 16-row (or 16-col) sub-tile `sub` of the wave's
 // 64-wide strip starting at `wbase`, k-step kk (0,1) of the 64-deep tile.
-template <int KS>
+template <int KS, int KSTRIDE = 256>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int wbase, int sub, int kk, int lane) {
   if (KS == 0) {
     const int row = wbase + sub * 16 + (lane & 15);
@@ -90,8 +92,8 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int wbase,
     const int k = kk * 32 + 8 * g + q;
     const int h = q | ((g & 1) << 2);
     const int s32 = (wbase >> 4) + sub;
-    const unsigned char* a0 = lds + k * 256 + ((s32 ^ h) << 5) + 8 * p;
-    return tr_frag(a0, a0 + 1024);
+    const unsigned char* a0 = lds + k * KSTRIDE + ((s32 ^ h) << 5) + 8 * p;
+    return tr_frag(a0, a0 + 4 * KSTRIDE);
   }
 }
 
@@ -102,7 +104,7 @@ __device__ __forceinline__ void epilogue_rowstats(const pgca_gemm_args& a, f32x4
                                                   int wm, int wn, int lane) {
   const int rbase = m0 + wm * 64 + (lane >> 4) * 4;
   const int cbase = n0 + wn * 64 + (lane & 15);
-  const int part = tn * 2 + wn;
+  const int part = (n0 >> 6) + wn;  // one partial per 64-column strip
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -403,6 +405,191 @@ __global__ void rowstats_combine_kernel(const float* __restrict__ smax, const fl
   }
 }
 
+
+// ================================================================================================
+// 256 x 256 x 64 tile, 8 waves (2 x 4, each 128 x 64), operands brought in by LDS-DMA
+// (buffer_load ... lds, 16 B per lane, 1 KiB per wave-instruction) into a double-buffered 128 KiB
+// LDS image: no VGPR staging and no ds_write traffic - on gfx950 the VGPR->LDS write path
+// (~79 B/clk/CU for ds_write_b128) plus the fragment reads saturate the LDS port at the 128^2 tile.
+// The LDS image of each DMA instruction is lane-linear, so the XOR swizzles are applied to the
+// SOURCE address (same involution as the fragment readers).  Edges: M/N by clamping the source
+// row/column (clamped rows only feed outputs the epilogue masks), K must be a multiple of 64.
+// ================================================================================================
+// Runtime epilogue selection for one 64 x 64 accumulator block whose first row is `mh` (wave column wn).
+__device__ __forceinline__ void run_epilogue(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int mh,
+                                             int n0, int tn, int wn, int lane, int wave) {
+  switch (a.epilogue) {
+    case PGCA_EPI_ROWSTATS: epilogue_rowstats(a, acc, mh, n0, tn, 0, wn, lane); break;
+    case PGCA_EPI_GELU_NEW: epilogue_store<PGCA_EPI_GELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_QUICK_GELU: epilogue_store<PGCA_EPI_QUICK_GELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_RELU: epilogue_store<PGCA_EPI_RELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_TANH: epilogue_store<PGCA_EPI_TANH>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_DGELU_NEW: epilogue_store<PGCA_EPI_DGELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_DRELU: epilogue_store<PGCA_EPI_DRELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_DTANH: epilogue_store<PGCA_EPI_DTANH>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+  }
+}
+
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int TILE2_BYTES = 256 * 64 * 2;
+
+template <int KS>
+struct Dma {
+  unsigned goff[4];
+  __device__ __forceinline__ void init(int lane, int wave, int ld, int origin, int extent) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = wave * 4 + i;  // 1-KiB piece of the 32-KiB tile image
+      if (KS == 0) {               // [256 rows][64 k]: piece = 8 rows x 128 B
+        const int r = 8 * j + (lane >> 3);
+        const int c = (lane & 7) ^ (lane >> 3);
+        const int rg = min(origin + r, extent - 1) - origin;
+        goff[i] = (unsigned)(rg * ld + c * 8) * 2u;
+      } else {                     // [64 k][256 cols]: piece = 2 k-rows x 512 B
+        const int k = 2 * j + (lane >> 5);
+        const int c16 = lane & 31;
+        const int h = (k & 3) | (((k >> 3) & 1) << 2);
+        const int col = (((c16 >> 1) ^ h) << 4) + ((c16 & 1) << 3);
+        const int cg = min(origin + col, extent - 8) - origin;
+        goff[i] = (unsigned)(k * ld + cg) * 2u;
+      }
+    }
+  }
+  // The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA as a pending LDS write and
+  // drains it (s_waitcnt vmcnt(0)) in front of the next ds_read, which would serialise the copy of tile t+1 with
+  // the MFMAs of tile t.  Untracked, it stays in flight across the whole compute phase; dma_wait() retires it
+  // right before the barrier that hands the buffer to the readers.  (M0 = LDS byte address of lane 0's 16 bytes.)
+  __device__ __forceinline__ void issue(const bf16_t* base, unsigned char* tile, int wave) const {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 rs;
+    rs[0] = (unsigned)b;
+    rs[1] = (unsigned)(b >> 32) & 0xffffu;
+    rs[2] = 0x7ffffff0u;
+    rs[3] = 0x00020000u;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(tile) + (unsigned)wave * 4096u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                   :
+                   : "s"(lds0 + i * 1024u), "v"(goff[i]), "s"(rs)
+                   : "memory");
+    }
+  }
+};
+
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int LA>
+__device__ __forceinline__ void mma_half(const unsigned char* la, int row0, int kk, int lane, const bf16x8 (&fb)[4],
+                                         f32x4 (&acc)[4][4]) {
+  bf16x8 fa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA, 512>(la, row0, i, kk, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a, int ntm, int ntn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [2 stages][A | B][32 KiB]
+
+  const int nwg = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * ntn;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(GROUP_M, ntm - first_m);
+  const int in_group = bid - group * per_group;
+  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
+  const int nrows_b = a.epilogue == PGCA_EPI_DLOGITS ? a.N : a.N;
+
+  Dma<LA> da;
+  Dma<LB> db;
+  da.init(lane, wave, a.lda, m0, LA == 0 ? a.M : ((a.M + 7) & ~7));
+  db.init(lane, wave, a.ldb, n0, LB == 0 ? nrows_b : ((nrows_b + 7) & ~7));
+  const bf16_t* abase = LA == 0 ? A + (size_t)m0 * a.lda : A + m0;
+  const bf16_t* bbase = LB == 0 ? B + (size_t)n0 * a.ldb : B + n0;
+  const size_t astep = LA == 0 ? (size_t)BK : (size_t)BK * a.lda;
+  const size_t bstep = LB == 0 ? (size_t)BK : (size_t)BK * a.ldb;
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.K / BK;
+  da.issue(abase, smem2, wave);
+  db.issue(bbase, smem2 + TILE2_BYTES, wave);
+  dma_wait();
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      unsigned char* nxt = smem2 + (cur ^ 1) * 2 * TILE2_BYTES;
+      da.issue(abase + (size_t)(kt + 1) * astep, nxt, wave);
+      db.issue(bbase + (size_t)(kt + 1) * bstep, nxt + TILE2_BYTES, wave);
+    }
+    const unsigned char* la = smem2 + cur * 2 * TILE2_BYTES;
+    const unsigned char* lb = la + TILE2_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB, 512>(lb, wn * 64, j, kk, lane);
+      mma_half<LA>(la, wm * 128, kk, lane, fb, acc[0]);
+      mma_half<LA>(la, wm * 128 + 64, kk, lane, fb, acc[1]);
+    }
+    dma_wait();       // tile kt+1 has landed (this wave's pieces) ...
+    __syncthreads();  // ... and every wave is done reading tile kt
+  }
+
+  run_epilogue(a, acc[0], smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
+  run_epilogue(a, acc[1], smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
+}
+
+constexpr size_t GEMM256_LDS = 4 * TILE2_BYTES;  // 128 KiB
+
+int ensure_gemm256_attr() {
+  static int done = 0;
+  if (!done) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm256_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    hipError_t e3 = hipFuncSetAttribute((const void*)gemm256_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("gemm256: cannot raise dynamic LDS limit");
+      return PGCA_ERR_LAUNCH;
+    }
+    done = 1;
+  }
+  return PGCA_OK;
+}
+
 }  // namespace
 
 extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
@@ -450,9 +637,26 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
     }
   }
   const int ncols = a.epilogue == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
+  hipStream_t s = (hipStream_t)stream;
+  {
+    // big, K-aligned problems take the 256^2 LDS-DMA kernel; everything else the general 128^2 one
+    const int ntm2 = (a.M + BM2 - 1) / BM2, ntn2 = (ncols + BN2 - 1) / BN2;
+    const char* force = getenv("PGCA_GEMM_TILE");
+    const bool want256 = force ? atoi(force) == 256 : (ntm2 * ntn2 >= 192);
+    if ((a.K % BK) == 0 && want256 && a.M >= 8 && ncols >= 8) {
+      if (ensure_gemm256_attr()) return PGCA_ERR_LAUNCH;
+      dim3 grid2(ntm2 * ntn2), block2(512);
+      switch (a.layout) {
+        case PGCA_NT: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, a, ntm2, ntn2); break;
+        case PGCA_NN: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, a, ntm2, ntn2); break;
+        case PGCA_TN: hipLaunchKernelGGL((gemm256_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, a, ntm2, ntn2); break;
+        default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
+      }
+      return check_launch("pgca_gemm_bf16(256)");
+    }
+  }
   const int ntm = (a.M + BM - 1) / BM, ntn = (ncols + BN - 1) / BN;
   dim3 grid(ntm * ntn), block(256);
-  hipStream_t s = (hipStream_t)stream;
   switch (a.layout) {
     case PGCA_NT: hipLaunchKernelGGL((gemm_kernel<0, 0>), grid, block, 0, s, a, ntm, ntn); break;
     case PGCA_NN: hipLaunchKernelGGL((gemm_kernel<0, 1>), grid, block, 0, s, a, ntm, ntn); break;

@@ -46,13 +46,25 @@ def operands(layout, M, N, K, seed):
     return a, b, A, B
 
 
-SHAPES = [(128, 128, 64), (256, 384, 1024), (200, 136, 72), (77, 1000, 128), (1, 8, 8), (130, 264, 200)]
+SHAPES = [(128, 128, 64), (256, 384, 1024), (200, 136, 72), (77, 1000, 128), (1, 8, 8), (130, 264, 200),
+          (512, 768, 256), (300, 520, 192), (1000, 1000, 64)]
+
+
+@pytest.fixture(params=[128, 256])
+def tile(request):
+    """Force the 128^2 register-staged kernel or the 256^2 LDS-DMA kernel (the latter needs K % 64 == 0)."""
+    import os
+    os.environ["PGCA_GEMM_TILE"] = str(request.param)
+    yield request.param
+    os.environ.pop("PGCA_GEMM_TILE", None)
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("shape", SHAPES)
-def test_gemm_layouts_and_edges(hip, layout, shape):
+def test_gemm_layouts_and_edges(hip, tile, layout, shape):
     M, N, K = shape
+    if tile == 256 and (K % 64 or M < 8):
+        pytest.skip("256^2 kernel is only dispatched for K % 64 == 0")
     if layout == 2 and M % 8:   # TN: A is [K, M], row stride must be a multiple of 8 elements
         ldm = (M + 7) // 8 * 8
     else:
@@ -79,9 +91,9 @@ def test_gemm_layouts_and_edges(hip, layout, shape):
     close(out_b, ref, 1.0 / 128, "bf16 out")
 
 
-def test_gemm_asymmetric_identity(hip):
+def test_gemm_asymmetric_identity(hip, tile):
     """A = I with asymmetric B catches a swapped row/col map in the C write."""
-    n = 128
+    n = 128 if tile == 128 else 512
     eye = torch.eye(n, device=dev()).bfloat16()
     b = (torch.arange(n * n, device=dev()).float().view(n, n) % 251 - 125).bfloat16()
     for layout in (0, 1, 2):
@@ -92,7 +104,7 @@ def test_gemm_asymmetric_identity(hip):
 
 
 @pytest.mark.parametrize("epi", ["gelu", "quick_gelu", "relu", "tanh"])
-def test_gemm_activation_epilogues(hip, epi):
+def test_gemm_activation_epilogues(hip, tile, epi):
     M, N, K = 192, 320, 256
     a, b, A, B = operands(1, M, N, K, seed=3)
     bias = rnd(N, seed=9)
@@ -107,7 +119,7 @@ def test_gemm_activation_epilogues(hip, epi):
         close(aux, pre, 1.0 / 128, "pre-activation")
 
 
-def test_gemm_derivative_epilogues_residual_accumulate(hip):
+def test_gemm_derivative_epilogues_residual_accumulate(hip, tile):
     M, N, K = 160, 256, 128
     a, b, A, B = operands(0, M, N, K, seed=21)
     acc = a.float() @ b.float()
@@ -132,7 +144,7 @@ def test_gemm_derivative_epilogues_residual_accumulate(hip):
     close(stream, 1.5 * acc + res, 2e-4, "accumulate")
 
 
-def test_lm_head_rowstats_and_dlogits(hip):
+def test_lm_head_rowstats_and_dlogits(hip, tile):
     """Fused LM head: log-prob gather without logits in HBM (model.py:1069-1079), and the
     recomputed dlogits = g * (softmax - onehot)."""
     M, V, K = 150, 1004, 128          # V not a multiple of 8 or of the 128 tile

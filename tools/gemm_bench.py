@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the MFMA GEMM on the shapes of the GPT-2-M DPO step (random bf16 data).
+
+    python tools/gemm_bench.py [--tile 128|256] [--iters 20] [--only NAME]
+
+Prints TFLOP/s per shape; used with rocprofv3 --pmc to read LDS-conflict / MFMA-busy counters.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pgca_amd import hip  # noqa: E402
+
+SHAPES = [  # name, layout, M, N, K, epilogue
+    ("qkv_fwd", hip.NN, 16384, 3072, 1024, "bias"),
+    ("proj_fwd", hip.NN, 16384, 1024, 1024, "res"),
+    ("fc_fwd", hip.NN, 16384, 4096, 1024, "gelu"),
+    ("fc2_fwd", hip.NN, 16384, 1024, 4096, "res"),
+    ("fc2_dgrad", hip.NT, 16384, 4096, 1024, "dgelu"),
+    ("fc_dgrad", hip.NT, 16384, 1024, 4096, "none"),
+    ("fc_wgrad", hip.TN, 1024, 4096, 16384, "acc"),
+    ("fc2_wgrad", hip.TN, 4096, 1024, 16384, "acc"),
+    ("qkv_wgrad", hip.TN, 1024, 3072, 16384, "acc"),
+    ("lm_head", hip.NT, 9216, 50260, 1024, "rowstats"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    if args.tile:
+        os.environ["PGCA_GEMM_TILE"] = str(args.tile)
+    dev = torch.device("cuda:0")
+    hip.load()
+    for name, layout, M, N, K, epi in SHAPES:
+        if args.only and args.only != name:
+            continue
+        g = torch.Generator(device="cpu").manual_seed(1)
+        a_shape = (M, K) if layout != hip.TN else (K, M)
+        b_shape = (N, K) if layout == hip.NT else (K, N)
+        A = (torch.rand(a_shape, generator=g) * 2 - 1).to(dev).bfloat16()
+        B = (torch.rand(b_shape, generator=g) * 2 - 1).to(dev).bfloat16()
+        kw = {}
+        if epi in ("bias", "gelu", "res"):
+            kw["bias"] = torch.zeros(N, device=dev)
+        if epi in ("bias", "none"):
+            kw["out_bf16"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        if epi == "gelu":
+            kw.update(epilogue=hip.EPI_GELU_NEW, out_bf16=torch.empty(M, N, dtype=torch.bfloat16, device=dev),
+                      aux_out=torch.empty(M, N, dtype=torch.bfloat16, device=dev))
+        if epi == "dgelu":
+            kw.update(epilogue=hip.EPI_DGELU_NEW, out_bf16=torch.empty(M, N, dtype=torch.bfloat16, device=dev),
+                      aux_in=torch.zeros(M, N, dtype=torch.bfloat16, device=dev))
+        if epi == "res":
+            r = torch.zeros(M, N, device=dev)
+            kw.update(residual=r, out_f32=torch.empty(M, N, device=dev))
+        if epi == "acc":
+            kw.update(out_f32=torch.zeros(M, N, device=dev), accumulate=True)
+        if epi == "rowstats":
+            nparts = 2 * ((N + 127) // 128)
+            kw.update(epilogue=hip.EPI_ROWSTATS, targets=torch.zeros(M, dtype=torch.int64, device=dev),
+                      stat_max=torch.empty(M, nparts, device=dev), stat_sum=torch.empty(M, nparts, device=dev),
+                      stat_ld=nparts, target_val=torch.empty(M, device=dev))
+
+        def run():
+            hip.gemm(A, B, M, N, K, layout, **kw)
+
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / args.iters
+        print(f"{name:10s} layout={layout} M={M:6d} N={N:6d} K={K:6d} {epi:8s} {us:9.1f} us  "
+              f"{2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
