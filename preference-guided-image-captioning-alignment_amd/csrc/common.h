@@ -43,26 +43,23 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// tanh via exp: 1 - 2/(e^{2u}+1); saturates correctly for |u| large.
-__device__ __forceinline__ float fast_tanh(float u) {
-  float e = __expf(2.0f * u);
-  return 1.0f - 2.0f / (e + 1.0f);
-}
-// HF NewGELUActivation (transformers/activations.py:59-66)
+// sigma(z) with one v_exp and one v_rcp (saturates correctly: exp -> inf => 0, exp -> 0 => 1).
+__device__ __forceinline__ float fast_sigmoid(float z) { return __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+__device__ __forceinline__ float fast_tanh(float u) { return 2.0f * fast_sigmoid(2.0f * u) - 1.0f; }
+// HF NewGELUActivation (transformers/activations.py:59-66): 0.5 x (1 + tanh(u)) == x sigma(2u),
+// u = sqrt(2/pi) (x + 0.044715 x^3).  Written through sigma so the epilogue costs ~8 VALU ops per element.
 __device__ __forceinline__ float gelu_new(float x) {
-  const float k = 0.7978845608028654f;
-  float u = k * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.0f + fast_tanh(u));
+  const float k2 = 2.0f * 0.7978845608028654f;
+  return x * fast_sigmoid(k2 * x * (1.0f + 0.044715f * x * x));
 }
 __device__ __forceinline__ float dgelu_new(float x) {
-  const float k = 0.7978845608028654f;
-  float x2 = x * x;
-  float u = k * (x + 0.044715f * x * x2);
-  float t = fast_tanh(u);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k * (1.0f + 3.0f * 0.044715f * x2);
+  const float k2 = 2.0f * 0.7978845608028654f;
+  const float x2 = x * x;
+  const float s = fast_sigmoid(k2 * x * (1.0f + 0.044715f * x2));
+  return s + x * s * (1.0f - s) * k2 * (1.0f + 3.0f * 0.044715f * x2);
 }
 // HF QuickGELUActivation (transformers/activations.py:117-123)
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float quick_gelu(float x) { return x * fast_sigmoid(1.702f * x); }
 
 // Two transposed LDS reads -> one MFMA 16x16x32 fragment from a [k][m] (k-strided) image.
 // addr0 points at row (kbase + q), addr1 at row (kbase + 4 + q) of the 4x16 blocks (see gemm.hip).

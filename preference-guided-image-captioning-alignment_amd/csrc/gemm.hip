@@ -260,6 +260,17 @@ __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&
         for (int r = 0; r < 4; ++r)
           cbuf[(mh * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = acc[half * 2 + mh][ni][r];
     __syncthreads();
+    if (EPI == PGCA_EPI_NONE && a.accumulate == 2) {
+      // split-K partial: f32 atomic adds, one 256-byte row segment of the tile per wave-instruction
+      // (the access shape at which global_atomic_add_f32 runs at its full memory-side rate)
+      const int col = n0 + wn * 64 + lane;
+      if (col < a.N) {
+        for (int lr = 0; lr < 32; ++lr) {
+          const int row = m0 + wm * 64 + half * 32 + lr;
+          if (row < a.M) atomicAdd(a.out_f32 + (size_t)row * a.ld_out_f32 + col, a.alpha * cbuf[lr * LDC + lane]);
+        }
+      }
+    } else {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int lr = it * 8 + (lane >> 3);
@@ -279,6 +290,7 @@ __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&
         const int nv = ncols - col < 8 ? ncols - col : 8;
         finish8<EPI>(a, row, col, v, nv, lse, rscale, tgt);
       }
+    }
     }
     __syncthreads();
   }
@@ -494,7 +506,7 @@ __device__ __forceinline__ void mma_half(const unsigned char* la, int row0, int 
 }
 
 template <int LA, int LB>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a, int ntm, int ntn) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [2 stages][A | B][32 KiB]
 
   const int nwg = ntm * ntn;
@@ -538,7 +550,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a,
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = a.K / BK;
+  // split-K: blockIdx.y owns K tiles [kt0, kt0 + nk) and adds its partial with f32 atomics (accumulate == 2)
+  const int kt0 = blockIdx.y * nk_per_split;
+  const int nk = min(nk_per_split, a.K / BK - kt0);
+  abase += (size_t)kt0 * astep;
+  bbase += (size_t)kt0 * bstep;
   da.issue(abase, smem2, wave);
   db.issue(bbase, smem2 + TILE2_BYTES, wave);
   dma_wait();
@@ -642,14 +658,29 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
     // big, K-aligned problems take the 256^2 LDS-DMA kernel; everything else the general 128^2 one
     const int ntm2 = (a.M + BM2 - 1) / BM2, ntn2 = (ncols + BN2 - 1) / BN2;
     const char* force = getenv("PGCA_GEMM_TILE");
-    const bool want256 = force ? atoi(force) == 256 : (ntm2 * ntn2 >= 192);
+    // gradient-accumulating GEMMs with few output tiles but a long K (weight gradients: K = tokens) are split
+    // along K so the 256^2 kernel still fills the chip; partials meet through f32 atomics
+    const int nk_total = a.K / BK;
+    int splits = 1;
+    const bool splittable = a.epilogue == PGCA_EPI_NONE && a.accumulate && a.out_f32 && !a.out_bf16 && !a.bias &&
+                            !a.residual;
+    if (splittable && ntm2 * ntn2 < 192) {
+      splits = 256 / (ntm2 * ntn2);
+      if (splits > nk_total / 8) splits = nk_total / 8;
+      if (splits > 16) splits = 16;
+      if (splits < 1) splits = 1;
+    }
+    const bool want256 = force ? atoi(force) == 256 : (ntm2 * ntn2 * splits >= 192);
     if ((a.K % BK) == 0 && want256 && a.M >= 8 && ncols >= 8) {
       if (ensure_gemm256_attr()) return PGCA_ERR_LAUNCH;
-      dim3 grid2(ntm2 * ntn2), block2(512);
+      pgca_gemm_args b = a;
+      if (splits > 1) b.accumulate = 2;
+      const int nkps = (nk_total + splits - 1) / splits;
+      dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
       switch (a.layout) {
-        case PGCA_NT: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, a, ntm2, ntn2); break;
-        case PGCA_NN: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, a, ntm2, ntn2); break;
-        case PGCA_TN: hipLaunchKernelGGL((gemm256_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, a, ntm2, ntn2); break;
+        case PGCA_NT: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+        case PGCA_NN: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+        case PGCA_TN: hipLaunchKernelGGL((gemm256_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
         default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
       }
       return check_launch("pgca_gemm_bf16(256)");

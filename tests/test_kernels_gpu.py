@@ -427,3 +427,18 @@ def test_bad_arguments_raise(hip):
         hip.gemm(a, a, 8, 8, 4, 0, lda=8, ldb=8, out_f32=torch.zeros(8, 8, device=dev()))
     with pytest.raises(RuntimeError, match="S must be"):
         hip.attention_fwd(a, None, 1, 200, 1, True, a)
+
+
+def test_gemm_split_k_wgrad(hip):
+    """Weight-gradient shape (few output tiles, long K): the 256^2 kernel splits K and adds partials with
+    f32 atomics; the result must equal the accumulate semantics of the un-split kernel."""
+    for (M, N, K) in ((1024, 1024, 8192), (256, 520, 4096), (1024, 3072, 16384)):
+        a, b, A, B = operands(2, M, N, K, seed=K)
+        ldb = None
+        if N % 8:
+            pytest.skip("unused")
+        init = rnd(M, N, seed=3)
+        out = init.clone()
+        hip.gemm(A, B, M, N, K, hip.TN, out_f32=out, accumulate=True)
+        ref = init + a.float() @ b.float()
+        close(out, ref, 3e-4, f"split-K wgrad {M}x{N}x{K}")
