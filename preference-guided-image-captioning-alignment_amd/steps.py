@@ -101,7 +101,8 @@ class DPOStep:
 
     def __init__(self, store: ParamStore, ws: Workspace, vit: VisionTower, vhead: ProjHead,
                  dec: CaptionDecoderEngine, beta: float = 0.1, reference_free: bool = False,
-                 label_smoothing: float = 0.0, reduce: Optional[str] = None, ref: Optional[ReferencePolicy] = None):
+                 label_smoothing: float = 0.0, reduce: Optional[str] = None, ref: Optional[ReferencePolicy] = None,
+                 ref_side_stream: bool = False):
         self.store, self.ws, self.vit, self.vhead, self.dec = store, ws, vit, vhead, dec
         self.beta, self.reference_free, self.ls = float(beta), bool(reference_free), float(label_smoothing)
         # trainer parity: 2-forward == PreferenceLoss (length-mean); 4-forward == DPOPreferenceLoss (length-sum)
@@ -112,6 +113,8 @@ class DPOStep:
         dev = ws.device
         self.loss = torch.zeros(1, dtype=F32, device=dev)
         self.metrics = torch.zeros(4, dtype=F32, device=dev)
+        self._ref_stream = None
+        self.ref_side_stream = bool(ref_side_stream)
 
     @staticmethod
     def prepare(batch: dict, device) -> dict:
@@ -130,14 +133,27 @@ class DPOStep:
         emb2 = self.ws.get("dpo.emb2", (2 * B, P), F32)
         emb2[:B].copy_(emb)
         emb2[B:].copy_(emb)
-        pol = self.dec.sequence_logprobs(emb2, sb, self.reduce, save)
         ref_lp = None
         if not self.reference_free:
-            remb = self.ref.head.forward(pooled_bf, B, False)
-            remb2 = self.ws.get("dpo.remb2", (2 * B, P), F32)
-            remb2[:B].copy_(remb)
-            remb2[B:].copy_(remb)
-            ref_lp = self.ref.dec.sequence_logprobs(remb2, sb, self.reduce, False)
+            # the frozen reference policy runs on its own HIP stream, concurrently with the policy forward:
+            # the two kernel sequences are independent, so one's store-bound epilogues and tile tails are
+            # filled by the other's MFMA main loops
+            main = torch.cuda.current_stream()
+            if not self.ref_side_stream:
+                self._ref_stream = main
+            elif self._ref_stream is None or self._ref_stream is main:
+                self._ref_stream = torch.cuda.Stream()
+            if self._ref_stream is not main:
+                self._ref_stream.wait_stream(main)
+            with torch.cuda.stream(self._ref_stream):
+                remb = self.ref.head.forward(pooled_bf, B, False)
+                remb2 = self.ws.get("dpo.remb2", (2 * B, P), F32)
+                remb2[:B].copy_(remb)
+                remb2[B:].copy_(remb)
+                ref_lp = self.ref.dec.sequence_logprobs(remb2, sb, self.reduce, False)
+        pol = self.dec.sequence_logprobs(emb2, sb, self.reduce, save)
+        if ref_lp is not None and self._ref_stream is not torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_stream(self._ref_stream)
         return pol, ref_lp
 
     def loss_and_grads(self, images: torch.Tensor, sb: SeqBatch, loss_scale: float = 1.0) -> torch.Tensor:
