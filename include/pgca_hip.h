@@ -94,6 +94,9 @@ typedef struct pgca_gemm_args {
 } pgca_gemm_args;
 
 int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
+/* Which kernel pgca_gemm_bf16 would launch for these arguments: tile*100 + K-splits
+ * (12801 = general 128^2 register-staged kernel, 256xx = 256^2 LDS-DMA kernel with xx K-splits). */
+int pgca_gemm_plan(const pgca_gemm_args* args);
 
 /* Per-row combine of ROWSTATS partials: lse[m] = log sum exp over all columns;
  * out_logprob[m] = target_val[m] - lse[m] (token log-prob, reference model.py:1074-1079). */

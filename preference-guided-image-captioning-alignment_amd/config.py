@@ -1,0 +1,89 @@
+"""YAML configuration with dotted access, the surface the reference's trainer and CLI read
+(reference utils/config.py: ``Config(path)``, ``.get("a.b.c", default)``, ``.set``, ``get_stage{1,2}_config``,
+``PGCA_*``-style environment overrides).  It parses the reference's ``configs/*.yaml`` unchanged and adds an
+optional ``mi355x:`` section whose defaults reproduce the reference's behaviour.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Any, Dict, Optional
+
+import yaml
+
+REQUIRED_SECTIONS = ("model", "training")
+
+MI355X_DEFAULTS = {
+    "dpo": {"reference_free": True, "label_smoothing": 0.0},   # True = the reference trainer's 2-forward loss
+    "stage1": {"global_negatives": False},                      # False = local negatives, as the reference
+    "allreduce_bucket_elems": 64 * 1024 * 1024,
+    "allreduce_layer_group": 4,
+    "clip_every_micro_step": False,                             # reference quirk
+}
+
+
+class Config:
+    def __init__(self, config_path: Optional[str] = None) -> None:
+        if config_path is None:
+            config_path = str(Path(__file__).resolve().parent.parent / "configs" / "default.yaml")
+        self.config_path = Path(config_path)
+        with open(self.config_path, "r", encoding="utf-8") as f:
+            self.config: Dict[str, Any] = yaml.safe_load(f) or {}
+        for sec in REQUIRED_SECTIONS:
+            if sec not in self.config:
+                raise ValueError(f"Missing required configuration section: {sec}")
+        for st in ("stage1", "stage2"):
+            if st not in self.config["training"]:
+                raise ValueError(f"Missing required configuration section: training.{st}")
+        self._apply_env_overrides()
+
+    def _apply_env_overrides(self) -> None:
+        """``PGCA_<SECTION>__<KEY>[__<SUBKEY>]=value`` overrides a leaf (values parsed as YAML scalars)."""
+        for k, v in os.environ.items():
+            if not k.startswith("PGCA_CFG_"):
+                continue
+            path = k[len("PGCA_CFG_"):].lower().split("__")
+            self.set(".".join(path), yaml.safe_load(v))
+
+    def get(self, path: str, default: Any = None) -> Any:
+        cur: Any = self.config
+        try:
+            for key in path.split("."):
+                cur = cur[key]
+            return cur
+        except (KeyError, TypeError):
+            if path.startswith("mi355x."):
+                cur = MI355X_DEFAULTS
+                try:
+                    for key in path.split(".")[1:]:
+                        cur = cur[key]
+                    return cur
+                except (KeyError, TypeError):
+                    return default
+            return default
+
+    def set(self, path: str, value: Any) -> None:
+        keys = path.split(".")
+        cur = self.config
+        for key in keys[:-1]:
+            cur = cur.setdefault(key, {})
+        cur[keys[-1]] = value
+
+    def get_model_config(self) -> Dict[str, Any]:
+        return self.config["model"]
+
+    def get_training_config(self) -> Dict[str, Any]:
+        return self.config["training"]
+
+    def get_stage1_config(self) -> Dict[str, Any]:
+        return self.config["training"]["stage1"]
+
+    def get_stage2_config(self) -> Dict[str, Any]:
+        return self.config["training"]["stage2"]
+
+    def save(self, path: Optional[str] = None) -> None:
+        with open(path or self.config_path, "w", encoding="utf-8") as f:
+            yaml.safe_dump(self.config, f, default_flow_style=False, indent=2)
+
+    def __repr__(self) -> str:
+        return f"Config({self.config_path})"

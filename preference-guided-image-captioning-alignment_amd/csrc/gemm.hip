@@ -606,7 +606,35 @@ int ensure_gemm256_attr() {
   return PGCA_OK;
 }
 
+// Kernel choice: big, K-aligned problems take the 256^2 LDS-DMA kernel, everything else the general 128^2
+// one.  Gradient-accumulating GEMMs with few output tiles but a long K (weight gradients: K = tokens) are split
+// along K so the 256^2 kernel still fills the chip; partials meet through f32 atomics.
+int plan_tile(const pgca_gemm_args& a, int* splits_out) {
+  const int ncols = a.epilogue == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
+  const int ntm2 = (a.M + BM2 - 1) / BM2, ntn2 = (ncols + BN2 - 1) / BN2;
+  const char* force = getenv("PGCA_GEMM_TILE");
+  const int nk_total = a.K / BK;
+  int splits = 1;
+  const bool splittable = a.epilogue == PGCA_EPI_NONE && a.accumulate && a.out_f32 && !a.out_bf16 && !a.bias &&
+                          !a.residual;
+  if (splittable && ntm2 * ntn2 < 192) {
+    splits = 256 / (ntm2 * ntn2);
+    if (splits > nk_total / 8) splits = nk_total / 8;
+    if (splits > 16) splits = 16;
+    if (splits < 1) splits = 1;
+  }
+  const bool want256 = force ? atoi(force) == 256 : (ntm2 * ntn2 * splits >= 192);
+  *splits_out = splits;
+  return ((a.K % BK) == 0 && want256 && a.M >= 8 && ncols >= 8) ? 256 : 128;
+}
+
 }  // namespace
+
+extern "C" int pgca_gemm_plan(const pgca_gemm_args* args) {
+  int splits = 1;
+  const int tile = plan_tile(*args, &splits);
+  return tile * 100 + (tile == 256 ? splits : 1);
+}
 
 extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
   const pgca_gemm_args& a = *args;
@@ -655,23 +683,11 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
   const int ncols = a.epilogue == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
   hipStream_t s = (hipStream_t)stream;
   {
-    // big, K-aligned problems take the 256^2 LDS-DMA kernel; everything else the general 128^2 one
     const int ntm2 = (a.M + BM2 - 1) / BM2, ntn2 = (ncols + BN2 - 1) / BN2;
-    const char* force = getenv("PGCA_GEMM_TILE");
-    // gradient-accumulating GEMMs with few output tiles but a long K (weight gradients: K = tokens) are split
-    // along K so the 256^2 kernel still fills the chip; partials meet through f32 atomics
     const int nk_total = a.K / BK;
     int splits = 1;
-    const bool splittable = a.epilogue == PGCA_EPI_NONE && a.accumulate && a.out_f32 && !a.out_bf16 && !a.bias &&
-                            !a.residual;
-    if (splittable && ntm2 * ntn2 < 192) {
-      splits = 256 / (ntm2 * ntn2);
-      if (splits > nk_total / 8) splits = nk_total / 8;
-      if (splits > 16) splits = 16;
-      if (splits < 1) splits = 1;
-    }
-    const bool want256 = force ? atoi(force) == 256 : (ntm2 * ntn2 * splits >= 192);
-    if ((a.K % BK) == 0 && want256 && a.M >= 8 && ncols >= 8) {
+    const bool want256 = plan_tile(a, &splits) == 256;
+    if (want256) {
       if (ensure_gemm256_attr()) return PGCA_ERR_LAUNCH;
       pgca_gemm_args b = a;
       if (splits > 1) b.accumulate = 2;

@@ -44,6 +44,7 @@ class GemmArgs(C.Structure):
 # name -> argtypes (return type is always int status unless noted)
 _SIGS = {
     "pgca_gemm_bf16": [C.POINTER(GemmArgs), _vp],
+    "pgca_gemm_plan": [C.POINTER(GemmArgs)],
     "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_layernorm_bwd_blocks": [_i32],
@@ -138,7 +139,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
     a.target_val, a.row_lse, a.row_scale = _p(target_val), _p(row_lse), _p(row_scale)
     a.out_cols = out_cols
     probe = gemm_probe
-    if probe is not None and probe.want(layout, epilogue, M, N, K):
+    if probe is not None and probe.want(layout, epilogue, load().pgca_gemm_plan(C.byref(a)) // 100):
         # HIP events on the launch stream bracket this one kernel (bench.py roofline measurement)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
