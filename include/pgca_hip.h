@@ -126,6 +126,10 @@ int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x,
 /* out[h] (+)= sum_b part[b, h]; nparts rows of length H. */
 int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, float* out, int32_t accumulate, void* stream);
 
+/* Same for up to four planes part[plane][nparts][H] -> out0..out3 in one launch. */
+int pgca_colsum_finish4(const float* part, int32_t nplanes, int32_t nparts, int32_t H, float* out0, float* out1,
+                        float* out2, float* out3, int32_t accumulate, void* stream);
+
 /* Column sums of a bf16 / f32 matrix (bias gradients): out[n] (+)= sum_m x[m, n]. */
 int pgca_colsum_blocks(int32_t M);
 int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, int32_t ld, float* part, void* stream);

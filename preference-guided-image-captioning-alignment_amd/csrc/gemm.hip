@@ -585,6 +585,168 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a,
   run_epilogue(a, acc[1], smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring variant of the 256^2 kernel: BK = 32, FOUR LDS stages of (A 16 KiB | B 16 KiB), three K tiles
+// of LDS-DMA in flight.  Each wave retires only the OLDEST tile with a counted `s_waitcnt vmcnt(N)`
+// (N = 4 DMA instructions x tiles still allowed in flight) before the one barrier per tile, so HBM/L2
+// latency is covered by up to three tiles of MFMA work instead of one.
+// ------------------------------------------------------------------------------------------------
+constexpr int RBK = 32, RSTAGES = 4;
+constexpr int RTILE_BYTES = 256 * RBK * 2;  // 16 KiB per operand per stage
+
+__device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }  // {0,2,3,1}
+
+template <int KS>
+struct DmaR {
+  unsigned goff[2];
+  __device__ __forceinline__ void init(int lane, int wave, int ld, int origin, int extent) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = wave * 2 + i;  // 1-KiB piece of the 16-KiB tile image
+      if (KS == 0) {               // [256 rows][32 k]: piece = 16 rows x 64 B; chunk c of row r at c ^ swz4((r>>2)&3)
+        const int r = 16 * j + (lane >> 2);
+        const int c = (lane & 3) ^ swz4((lane >> 4) & 3);
+        const int rg = min(origin + r, extent - 1) - origin;
+        goff[i] = (unsigned)(rg * ld + c * 8) * 2u;
+      } else {                     // [32 k][256 cols]: piece = 2 k-rows x 512 B (same image as the BK = 64 kernel)
+        const int k = 2 * j + (lane >> 5);
+        const int c16 = lane & 31;
+        const int h = (k & 3) | (((k >> 3) & 1) << 2);
+        const int col = (((c16 >> 1) ^ h) << 4) + ((c16 & 1) << 3);
+        const int cg = min(origin + col, extent - 8) - origin;
+        goff[i] = (unsigned)(k * ld + cg) * 2u;
+      }
+    }
+  }
+  __device__ __forceinline__ void issue(const bf16_t* base, unsigned char* tile, int wave) const {
+    const unsigned long long b = (unsigned long long)base;
+    u32x4 rs;
+    rs[0] = (unsigned)b;
+    rs[1] = (unsigned)(b >> 32) & 0xffffu;
+    rs[2] = 0x7ffffff0u;
+    rs[3] = 0x00020000u;
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(tile) + (unsigned)wave * 2048u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                   :
+                   : "s"(lds0 + i * 1024u), "v"(goff[i]), "s"(rs)
+                   : "memory");
+    }
+  }
+};
+
+template <int KS>
+__device__ __forceinline__ bf16x8 read_frag_r(const unsigned char* lds, int wbase, int sub, int lane) {
+  if (KS == 0) {
+    const int row = wbase + sub * 16 + (lane & 15);
+    const int pos = (lane >> 4) ^ swz4((lane >> 2) & 3);
+    return *reinterpret_cast<const bf16x8*>(lds + row * 64 + pos * 16);
+  } else {
+    return read_frag<1, 512>(lds, wbase, sub, 0, lane);
+  }
+}
+
+template <int LA>
+__device__ __forceinline__ void mma_half_r(const unsigned char* la, int row0, int lane, const bf16x8 (&fb)[4],
+                                           f32x4 (&acc)[4][4]) {
+  bf16x8 fa[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa[i] = read_frag_r<LA>(la, row0, i, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(512, 2) void gemm256r_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [4 stages][A | B][16 KiB]
+
+  const int nwg = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * ntn;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(GROUP_M, ntm - first_m);
+  const int in_group = bid - group * per_group;
+  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
+
+  DmaR<LA> da;
+  DmaR<LB> db;
+  da.init(lane, wave, a.lda, m0, LA == 0 ? a.M : ((a.M + 7) & ~7));
+  db.init(lane, wave, a.ldb, n0, LB == 0 ? a.N : ((a.N + 7) & ~7));
+  const bf16_t* abase = LA == 0 ? A + (size_t)m0 * a.lda : A + m0;
+  const bf16_t* bbase = LB == 0 ? B + (size_t)n0 * a.ldb : B + n0;
+  const size_t astep = LA == 0 ? (size_t)RBK : (size_t)RBK * a.lda;
+  const size_t bstep = LB == 0 ? (size_t)RBK : (size_t)RBK * a.ldb;
+
+  f32x4 acc[2][4][4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // split-K in units of 64-deep tiles (two ring tiles each) like the BK = 64 kernel
+  const int kt0 = blockIdx.y * nk_per_split * 2;
+  const int nk = min(nk_per_split * 2, a.K / RBK - kt0);
+  abase += (size_t)kt0 * astep;
+  bbase += (size_t)kt0 * bstep;
+
+#pragma unroll
+  for (int p = 0; p < RSTAGES - 1; ++p) {
+    if (p < nk) {
+      da.issue(abase + (size_t)p * astep, smem2 + p * 2 * RTILE_BYTES, wave);
+      db.issue(bbase + (size_t)p * bstep, smem2 + p * 2 * RTILE_BYTES + RTILE_BYTES, wave);
+    }
+  }
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // tiles kt+1, kt+2 (if they exist) may stay in flight: 4 DMA instructions per tile per wave
+    const int rem = nk - 1 - kt;
+    if (rem >= 2) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (rem == 1) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();  // every wave's pieces of tile kt have landed; everyone is done reading tile kt-1
+    if (kt + RSTAGES - 1 < nk) {
+      unsigned char* nxt = smem2 + ((kt + RSTAGES - 1) & (RSTAGES - 1)) * 2 * RTILE_BYTES;
+      da.issue(abase + (size_t)(kt + RSTAGES - 1) * astep, nxt, wave);
+      db.issue(bbase + (size_t)(kt + RSTAGES - 1) * bstep, nxt + RTILE_BYTES, wave);
+    }
+    const unsigned char* la = smem2 + (kt & (RSTAGES - 1)) * 2 * RTILE_BYTES;
+    const unsigned char* lb = la + RTILE_BYTES;
+    bf16x8 fb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = read_frag_r<LB>(lb, wn * 64, j, lane);
+    mma_half_r<LA>(la, wm * 128, lane, fb, acc[0]);
+    mma_half_r<LA>(la, wm * 128 + 64, lane, fb, acc[1]);
+  }
+  __syncthreads();  // the epilogue stages through the same LDS
+
+  run_epilogue(a, acc[0], smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
+  run_epilogue(a, acc[1], smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
+}
+
 constexpr size_t GEMM256_LDS = 4 * TILE2_BYTES;  // 128 KiB
 
 int ensure_gemm256_attr() {
@@ -596,7 +758,14 @@ int ensure_gemm256_attr() {
                                         (int)GEMM256_LDS);
     hipError_t e3 = hipFuncSetAttribute((const void*)gemm256_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GEMM256_LDS);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    hipError_t e4 = hipFuncSetAttribute((const void*)gemm256r_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    hipError_t e5 = hipFuncSetAttribute((const void*)gemm256r_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    hipError_t e6 = hipFuncSetAttribute((const void*)gemm256r_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess ||
+        e6 != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm256: cannot raise dynamic LDS limit");
       return PGCA_ERR_LAUNCH;
@@ -693,6 +862,17 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       if (splits > 1) b.accumulate = 2;
       const int nkps = (nk_total + splits - 1) / splits;
       dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
+      const char* ring_env = getenv("PGCA_GEMM_RING");
+      const bool ring = ring_env ? atoi(ring_env) != 0 : false;  // measured: the 2-stage BK=64 loop is 5-10 % faster
+      if (ring) {
+        switch (a.layout) {
+          case PGCA_NT: hipLaunchKernelGGL((gemm256r_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          case PGCA_NN: hipLaunchKernelGGL((gemm256r_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          case PGCA_TN: hipLaunchKernelGGL((gemm256r_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
+        }
+        return check_launch("pgca_gemm_bf16(256 ring)");
+      }
       switch (a.layout) {
         case PGCA_NT: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
         case PGCA_NN: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;

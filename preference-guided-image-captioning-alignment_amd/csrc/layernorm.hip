@@ -350,6 +350,30 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
   }
 }
 
+// Up to four planes part[plane][b][c] folded into four outputs in one launch (blockIdx.y = plane).
+__global__ __launch_bounds__(256) void colsum_finish4_kernel(const float* __restrict__ part, int nparts, int H,
+                                                             float* o0, float* o1, float* o2, float* o3,
+                                                             int accumulate) {
+  __shared__ float red[8][32];
+  const int cx = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  const float* pl = part + (size_t)blockIdx.y * nparts * H;
+  float* out = blockIdx.y == 0 ? o0 : (blockIdx.y == 1 ? o1 : (blockIdx.y == 2 ? o2 : o3));
+  float s = 0.f;
+  if (c < H) {
+#pragma unroll 4
+    for (int b = sl; b < nparts; b += 8) s += pl[(size_t)b * H + c];
+  }
+  red[sl][cx] = s;
+  __syncthreads();
+  if (sl == 0 && c < H) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][cx];
+    out[c] = accumulate ? out[c] + t : t;
+  }
+}
+
 // part[blockIdx.y, n] = sum over this block's rows of x[m, n].  Block = 32 column groups (8 columns = one 16-B
 // bf16 load) x 8 row lanes; a block covers 256 columns x rows_per_blk rows; row lanes meet in LDS.
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ xb, const float* __restrict__ xf,
@@ -470,6 +494,18 @@ extern "C" int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, 
   hipLaunchKernelGGL(colsum_finish_kernel, dim3((H + 31) / 32), dim3(256), 0, (hipStream_t)stream, part, nparts, H,
                      out, accumulate);
   return check_launch("pgca_colsum_finish");
+}
+
+extern "C" int pgca_colsum_finish4(const float* part, int32_t nplanes, int32_t nparts, int32_t H, float* out0,
+                                   float* out1, float* out2, float* out3, int32_t accumulate, void* stream) {
+  if (!part || nplanes < 1 || nplanes > 4 || nparts <= 0 || H <= 0 || !out0 || (nplanes > 1 && !out1) ||
+      (nplanes > 2 && !out2) || (nplanes > 3 && !out3)) {
+    set_error("pgca_colsum_finish4: bad arguments");
+    return PGCA_ERR_INVALID;
+  }
+  hipLaunchKernelGGL(colsum_finish4_kernel, dim3((H + 31) / 32, nplanes), dim3(256), 0, (hipStream_t)stream, part,
+                     nparts, H, out0, out1, out2, out3, accumulate);
+  return check_launch("pgca_colsum_finish4");
 }
 
 extern "C" int pgca_colsum_blocks(int32_t M) {

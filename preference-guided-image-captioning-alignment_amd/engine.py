@@ -97,9 +97,9 @@ def _bias_grad(ws: Workspace, M: int, N: int, ld: int, gout: torch.Tensor, x_bf1
     hip.colsum_finish(part, nb, N, gout, accumulate=True)
 
 
-def _ln_param_grads(part: torch.Tensor, nb: int, H: int, gw: torch.Tensor, gb: torch.Tensor) -> None:
-    hip.colsum_finish(part[0], nb, H, gw, accumulate=True)
-    hip.colsum_finish(part[1], nb, H, gb, accumulate=True)
+def _ln_param_grads(part: torch.Tensor, nb: int, H: int, *outs: torch.Tensor) -> None:
+    """part [len(outs), nb, H] partial planes -> accumulated into the given gradient views (one launch)."""
+    hip.colsum_finish4(part, len(outs), nb, H, outs, accumulate=True)
 
 
 class _P:
@@ -191,8 +191,8 @@ class GptTrunk:
         M, Bq, S = sv["M"], sv["Bq"], sv["S"]
         ws = self.ws
         nb = hip.layernorm_bwd_blocks(M)
-        part = ws.get("ln_part", (2, nb, H), F32)
-        partx = ws.get("ln_partx", (2, nb, H), F32)
+        part4 = ws.get("ln_part", (4, nb, H), F32)   # planes: dgamma, dbeta, sum(add_to), sum(dx_out)
+        part, partx = part4[:2], part4[2:]
         for li in range(len(self.layers) - 1, -1, -1):
             P, s = self.layers[li], sv[li]
             # ---- MLP: h_out = hm + c_proj(gelu(c_fc(ln2(hm))))
@@ -207,9 +207,8 @@ class GptTrunk:
             g2_bf = self._buf("gbf_b" if (li & 1) else "gbf_a", (M, H), BF16)
             hip.layernorm_bwd(s["hm"], M, H, P["ln2w"].w, s["m2"], s["r2"], g2, dy_bf16=dln, add_to=g, dx_bf16=g2_bf,
                               part=part, part_extra=partx)
-            _ln_param_grads(part, nb, H, P["ln2w"].g, P["ln2b"].g)
             # the same pass summed g (bias gradient of mlp.c_proj) and g2 (bias gradient of attn.c_proj)
-            _ln_param_grads(partx, nb, H, P["bpr"].g, P["bo"].g)
+            _ln_param_grads(part4, nb, H, P["ln2w"].g, P["ln2b"].g, P["bpr"].g, P["bo"].g)
             # ---- attention: hm = hin + c_proj(attn(c_attn(ln1(hin))))
             datt = self._buf("datt", (M, H), BF16)
             hip.gemm(g2_bf, P["wo"].b, M, H, H, hip.NT, out_bf16=datt)
@@ -466,7 +465,7 @@ class CaptionDecoderEngine:
         # row_scale * (softmax - onehot), so it is fed -dLoss/dtok_lp
         rs.neg_()
         # LM head: dlogits recomputed tile by tile in row chunks
-        dhf = self._buf("dhf", (Mc, H), BF16)
+        dhf = self._buf("dhf32", (Mc, H), F32, zero=True)  # f32 + accumulate: lets the K = vocab dgrad GEMM split K
         ck = min(self.LM_CHUNK, Mc)
         dl = self._buf("dlogits", (ck, self.Vp), BF16)
         for r0 in range(0, Mc, ck):
@@ -475,14 +474,14 @@ class CaptionDecoderEngine:
             hip.gemm(hfc, self.wte.b, n, self.V, H, hip.NT, epilogue=hip.EPI_DLOGITS, targets=sb.targets[r0:r0 + n],
                      row_lse=s["lse"][r0:r0 + n], row_scale=rs[r0:r0 + n], out_bf16=dl, ld_out_bf16=self.Vp,
                      out_cols=self.Vp)
-            hip.gemm(dl, self.wte_pad_bf, n, H, self.Vp, hip.NN, lda=self.Vp, ldb=H, out_bf16=dhf[r0:r0 + n])
+            hip.gemm(dl, self.wte_pad_bf, n, H, self.Vp, hip.NN, lda=self.Vp, ldb=H, out_f32=dhf[r0:r0 + n], accumulate=True)
             hip.gemm(dl, hfc, self.V, H, n, hip.TN, lda=self.Vp, ldb=H, out_f32=self.wte.g, accumulate=True)
         # ln_f backward scatters to the scored rows; every other row of the stream gets zero gradient
         g = self.trunk._buf("g_top", (M, H), F32, zero=True)
         g_bf = self.trunk._buf("gbf_top", (M, H), BF16, zero=True)
         nb = hip.layernorm_bwd_blocks(Mc)
         part = ws.get("ln_part_f", (2, nb, H), F32)
-        hip.layernorm_bwd(s["hL"], Mc, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_bf16=dhf, row_map=sb.row_map,
+        hip.layernorm_bwd(s["hL"], Mc, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dhf, row_map=sb.row_map,
                           dx_bf16=g_bf, part=part)
         _ln_param_grads(part, nb, H, self.trunk.lnf_w.g, self.trunk.lnf_b.g)
         g0 = self.trunk.backward(g, g_bf)

@@ -50,6 +50,7 @@ _SIGS = {
     "pgca_layernorm_bwd_blocks": [_i32],
     "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pgca_colsum_finish": [_vp, _i32, _i32, _vp, _i32, _vp],
+    "pgca_colsum_finish4": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "pgca_colsum_blocks": [_i32],
     "pgca_colsum": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
@@ -179,6 +180,12 @@ def layernorm_bwd(x, M, H, gamma, mean, rstd, dx_out, *, dy_bf16=None, dy_f32=No
 def colsum_finish(part, nparts, H, out, accumulate=False):
     _check(load().pgca_colsum_finish(_p(part), nparts, H, _p(out), 1 if accumulate else 0, _stream()),
            "pgca_colsum_finish")
+
+
+def colsum_finish4(part, nplanes, nparts, H, outs, accumulate=False):
+    o = list(outs) + [None] * (4 - len(outs))
+    _check(load().pgca_colsum_finish4(_p(part), nplanes, nparts, H, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]),
+                                      1 if accumulate else 0, _stream()), "pgca_colsum_finish4")
 
 
 def colsum_blocks(M: int) -> int:

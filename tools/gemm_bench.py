@@ -33,9 +33,12 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--ring", type=int, default=-1)
     args = ap.parse_args()
     if args.tile:
         os.environ["PGCA_GEMM_TILE"] = str(args.tile)
+    if args.ring >= 0:
+        os.environ["PGCA_GEMM_RING"] = str(args.ring)
     dev = torch.device("cuda:0")
     hip.load()
     for name, layout, M, N, K, epi in SHAPES:
