@@ -94,8 +94,9 @@ typedef struct pgca_gemm_args {
 } pgca_gemm_args;
 
 int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
-/* Which kernel pgca_gemm_bf16 would launch for these arguments: tile*100 + K-splits
- * (12801 = general 128^2 register-staged kernel, 256xx = 256^2 LDS-DMA kernel with xx K-splits). */
+/* Which kernel pgca_gemm_bf16 would launch for these arguments: schedule*1000000 + tile*100 + K-splits
+ * (12801 = general 128^2 register-staged kernel; 256xx = 256^2 LDS-DMA kernel with xx K-splits, schedule
+ * 0 = 2-stage BK=64 loop (gemm256_kernel), 1 = ring, 2 = phased, 3 = phased ring (gemm256q_kernel)). */
 int pgca_gemm_plan(const pgca_gemm_args* args);
 
 /* Per-row combine of ROWSTATS partials: lse[m] = log sum exp over all columns;

@@ -747,6 +747,276 @@ __global__ __launch_bounds__(512, 2) void gemm256r_kernel(const pgca_gemm_args a
   run_epilogue(a, acc[1], smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Phased variant of the 256^2 kernel.  A 512-thread workgroup puts two waves on every SIMD (wave w and
+// w + 4).  Here the two halves of the workgroup (waves 0-3 = top 128 rows, waves 4-7 = bottom 128 rows)
+// run the SAME schedule one phase apart, every phase closed by one s_barrier:
+//     half 0:  R0  M0  R1  M1 | R0  M0 ...        R = fragment reads of one 32-deep k-step (LDS -> VGPR)
+//     half 1:      R0  M0  R1 | M1  R0 ...        M = its 32 MFMAs
+// so on each SIMD one wave always owns the matrix pipe while its partner fetches operands: the pipe
+// never waits for LDS latency and the two waves never fight for it.  The LDS-DMA of tile t+1 is issued
+// in the first phase of tile t and retired (vmcnt(0)) in its last phase: four phases of flight.
+// ------------------------------------------------------------------------------------------------
+#define PGCA_PHASE_BARRIER()              \
+  do {                                    \
+    __builtin_amdgcn_sched_barrier(0);    \
+    __builtin_amdgcn_s_barrier();         \
+    __builtin_amdgcn_sched_barrier(0);    \
+  } while (0)
+
+template <int LA, int LB>
+__device__ __forceinline__ void load_frags_p(const unsigned char* la, const unsigned char* lb, int arow0, int bcol0,
+                                             int kk, int lane, bf16x8 (&fa0)[4], bf16x8 (&fa1)[4], bf16x8 (&fb)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB, 512>(lb, bcol0, j, kk, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<LA, 512>(la, arow0, i, kk, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa1[i] = read_frag<LA, 512>(la, arow0 + 64, i, kk, lane);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void mma32_p(const bf16x8 (&fa0)[4], const bf16x8 (&fa1)[4], const bf16x8 (&fb)[4],
+                                        f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb[j], acc0[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb[j], acc1[i][j], 0, 0, 0);
+  __builtin_amdgcn_s_setprio(0);
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [2 stages][A | B][32 KiB]
+
+  const int nwg = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * ntn;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(GROUP_M, ntm - first_m);
+  const int in_group = bid - group * per_group;
+  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;  // wm doubles as the phase half
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
+
+  Dma<LA> da;
+  Dma<LB> db;
+  da.init(lane, wave, a.lda, m0, LA == 0 ? a.M : ((a.M + 7) & ~7));
+  db.init(lane, wave, a.ldb, n0, LB == 0 ? a.N : ((a.N + 7) & ~7));
+  const bf16_t* abase = LA == 0 ? A + (size_t)m0 * a.lda : A + m0;
+  const bf16_t* bbase = LB == 0 ? B + (size_t)n0 * a.ldb : B + n0;
+  const size_t astep = LA == 0 ? (size_t)BK : (size_t)BK * a.lda;
+  const size_t bstep = LB == 0 ? (size_t)BK : (size_t)BK * a.ldb;
+
+  f32x4 acc0[4][4], acc1[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int kt0 = blockIdx.y * nk_per_split;
+  const int nk = min(nk_per_split, a.K / BK - kt0);
+  abase += (size_t)kt0 * astep;
+  bbase += (size_t)kt0 * bstep;
+  da.issue(abase, smem2, wave);
+  db.issue(bbase, smem2 + TILE2_BYTES, wave);
+  dma_wait();
+  PGCA_PHASE_BARRIER();
+
+  const int arow0 = wm * 128, bcol0 = wn * 64;
+  bf16x8 fa0[4], fa1[4], fb[4];
+  if (wm == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* la = smem2 + (kt & 1) * 2 * TILE2_BYTES;
+      const unsigned char* lb = la + TILE2_BYTES;
+      if (kt + 1 < nk) {
+        unsigned char* nxt = smem2 + ((kt + 1) & 1) * 2 * TILE2_BYTES;
+        da.issue(abase + (size_t)(kt + 1) * astep, nxt, wave);
+        db.issue(bbase + (size_t)(kt + 1) * bstep, nxt + TILE2_BYTES, wave);
+      }
+      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 0, lane, fa0, fa1, fb);  // R0
+      PGCA_PHASE_BARRIER();
+      mma32_p(fa0, fa1, fb, acc0, acc1);                                   // M0
+      PGCA_PHASE_BARRIER();
+      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 1, lane, fa0, fa1, fb);  // R1
+      PGCA_PHASE_BARRIER();
+      mma32_p(fa0, fa1, fb, acc0, acc1);                                   // M1
+      dma_wait();
+      PGCA_PHASE_BARRIER();
+    }
+    PGCA_PHASE_BARRIER();  // the other half's trailing M1
+  } else {
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* la = smem2 + (kt & 1) * 2 * TILE2_BYTES;
+      const unsigned char* lb = la + TILE2_BYTES;
+      if (kt + 1 < nk) {
+        unsigned char* nxt = smem2 + ((kt + 1) & 1) * 2 * TILE2_BYTES;
+        da.issue(abase + (size_t)(kt + 1) * astep, nxt, wave);
+        db.issue(bbase + (size_t)(kt + 1) * bstep, nxt + TILE2_BYTES, wave);
+      }
+      if (kt > 0) mma32_p(fa0, fa1, fb, acc0, acc1);                       // M1 of the previous tile
+      PGCA_PHASE_BARRIER();
+      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 0, lane, fa0, fa1, fb);  // R0
+      PGCA_PHASE_BARRIER();
+      mma32_p(fa0, fa1, fb, acc0, acc1);                                   // M0
+      PGCA_PHASE_BARRIER();
+      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 1, lane, fa0, fa1, fb);  // R1
+      dma_wait();
+      PGCA_PHASE_BARRIER();
+    }
+    mma32_p(fa0, fa1, fb, acc0, acc1);                                     // M1 of the last tile
+    PGCA_PHASE_BARRIER();
+  }
+
+  run_epilogue(a, acc0, smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
+  run_epilogue(a, acc1, smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Phased ring: the two ideas together.  32-deep K tiles in a 4-stage LDS ring (three tiles of LDS-DMA
+// in flight, counted vmcnt) AND the two workgroup halves one phase apart, so that per 512-cycle phase
+// each SIMD has one wave issuing 32 MFMAs while its partner reads the next fragments and issues its
+// four 1-KiB DMA pieces - vector-memory issue (64 B/clk/CU through the texture path) never sits in
+// front of MFMAs in a wave's instruction stream.
+//     half 0:  R(0) M(0) R(1) M(1) ...
+//     half 1:   -   R(0) M(0) R(1) ...
+// ------------------------------------------------------------------------------------------------
+template <int LA, int LB>
+__device__ __forceinline__ void load_frags_q(const unsigned char* la, const unsigned char* lb, int arow0, int bcol0,
+                                             int lane, bf16x8 (&fa0)[4], bf16x8 (&fa1)[4], bf16x8 (&fb)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) fb[j] = read_frag_r<LB>(lb, bcol0, j, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa0[i] = read_frag_r<LA>(la, arow0, i, lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) fa1[i] = read_frag_r<LA>(la, arow0 + 64, i, lane);
+}
+
+__device__ __forceinline__ void wait_tiles_in_flight(int n) {  // n = later tiles that may stay in flight (0..2)
+  if (n >= 2) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else if (n == 1) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+}
+
+template <int LA, int LB>
+__global__ __launch_bounds__(512, 2) void gemm256q_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [4 stages][A | B][16 KiB]
+
+  const int nwg = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * ntn;
+  const int group = bid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsize = min(GROUP_M, ntm - first_m);
+  const int in_group = bid - group * per_group;
+  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
+  const int m0 = tm * BM2, n0 = tn * BN2;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
+  const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
+
+  DmaR<LA> da;
+  DmaR<LB> db;
+  da.init(lane, wave, a.lda, m0, LA == 0 ? a.M : ((a.M + 7) & ~7));
+  db.init(lane, wave, a.ldb, n0, LB == 0 ? a.N : ((a.N + 7) & ~7));
+  const bf16_t* abase = LA == 0 ? A + (size_t)m0 * a.lda : A + m0;
+  const bf16_t* bbase = LB == 0 ? B + (size_t)n0 * a.ldb : B + n0;
+  const size_t astep = LA == 0 ? (size_t)RBK : (size_t)RBK * a.lda;
+  const size_t bstep = LB == 0 ? (size_t)RBK : (size_t)RBK * a.ldb;
+
+  f32x4 acc0[4][4], acc1[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int kt0 = blockIdx.y * nk_per_split * 2;
+  const int nk = min(nk_per_split * 2, a.K / RBK - kt0);
+  abase += (size_t)kt0 * astep;
+  bbase += (size_t)kt0 * bstep;
+
+#pragma unroll
+  for (int p = 0; p < RSTAGES - 1; ++p) {
+    if (p < nk) {
+      da.issue(abase + (size_t)p * astep, smem2 + p * 2 * RTILE_BYTES, wave);
+      db.issue(bbase + (size_t)p * bstep, smem2 + p * 2 * RTILE_BYTES + RTILE_BYTES, wave);
+    }
+  }
+  wait_tiles_in_flight(min(2, nk - 1));
+  PGCA_PHASE_BARRIER();  // tile 0 is in LDS
+
+  const int arow0 = wm * 128, bcol0 = wn * 64;
+  bf16x8 fa0[4], fa1[4], fb[4];
+  if (wm == 0) {
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* la = smem2 + (kt & 3) * 2 * RTILE_BYTES;
+      load_frags_q<LA, LB>(la, la + RTILE_BYTES, arow0, bcol0, lane, fa0, fa1, fb);        // R(kt)
+      if (kt + 3 < nk) {
+        unsigned char* nxt = smem2 + ((kt + 3) & 3) * 2 * RTILE_BYTES;
+        da.issue(abase + (size_t)(kt + 3) * astep, nxt, wave);
+        db.issue(bbase + (size_t)(kt + 3) * bstep, nxt + RTILE_BYTES, wave);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PGCA_PHASE_BARRIER();
+      mma32_p(fa0, fa1, fb, acc0, acc1);                                                    // M(kt)
+      wait_tiles_in_flight(min(2, nk - 2 - kt));   // own pieces of tile kt+1 have landed
+      PGCA_PHASE_BARRIER();
+    }
+    PGCA_PHASE_BARRIER();  // the other half's trailing M
+  } else {
+    PGCA_PHASE_BARRIER();  // half 0 reads tile 0 first
+    for (int kt = 0; kt < nk; ++kt) {
+      const unsigned char* la = smem2 + (kt & 3) * 2 * RTILE_BYTES;
+      load_frags_q<LA, LB>(la, la + RTILE_BYTES, arow0, bcol0, lane, fa0, fa1, fb);        // R(kt)
+      if (kt + 3 < nk) {
+        unsigned char* nxt = smem2 + ((kt + 3) & 3) * 2 * RTILE_BYTES;
+        da.issue(abase + (size_t)(kt + 3) * astep, nxt, wave);
+        db.issue(bbase + (size_t)(kt + 3) * bstep, nxt + RTILE_BYTES, wave);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      wait_tiles_in_flight(min(2, nk - 2 - kt));   // own pieces of tile kt+1 have landed
+      PGCA_PHASE_BARRIER();
+      mma32_p(fa0, fa1, fb, acc0, acc1);                                                    // M(kt)
+      PGCA_PHASE_BARRIER();
+    }
+  }
+
+  run_epilogue(a, acc0, smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
+  run_epilogue(a, acc1, smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
+}
+
 constexpr size_t GEMM256_LDS = 4 * TILE2_BYTES;  // 128 KiB
 
 int ensure_gemm256_attr() {
@@ -764,8 +1034,21 @@ int ensure_gemm256_attr() {
                                         (int)GEMM256_LDS);
     hipError_t e6 = hipFuncSetAttribute((const void*)gemm256r_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GEMM256_LDS);
+    hipError_t e7 = hipFuncSetAttribute((const void*)gemm256p_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    hipError_t e8 = hipFuncSetAttribute((const void*)gemm256p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    hipError_t e9 = hipFuncSetAttribute((const void*)gemm256p_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    hipError_t e10 = hipFuncSetAttribute((const void*)gemm256q_kernel<0, 0>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM256_LDS);
+    hipError_t e11 = hipFuncSetAttribute((const void*)gemm256q_kernel<0, 1>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM256_LDS);
+    hipError_t e12 = hipFuncSetAttribute((const void*)gemm256q_kernel<1, 1>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM256_LDS);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess ||
-        e6 != hipSuccess) {
+        e6 != hipSuccess || e7 != hipSuccess || e8 != hipSuccess || e9 != hipSuccess || e10 != hipSuccess ||
+        e11 != hipSuccess || e12 != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm256: cannot raise dynamic LDS limit");
       return PGCA_ERR_LAUNCH;
@@ -799,10 +1082,21 @@ int plan_tile(const pgca_gemm_args& a, int* splits_out) {
 
 }  // namespace
 
+// Main-loop schedule of the 256^2 kernel: 0 = 2-stage BK=64, 1 = 4-stage BK=32 ring, 2 = phased halves,
+// 3 = phased ring.  Measured on MI355X (tools/gemm_bench.py): in isolation the phased ring wins on long-K NT/NN
+// (+5..9 % at K = 4096), the plain 2-stage loop on K = 1024 and on the K-strided TN weight gradients.
+static int plan_variant(const pgca_gemm_args& a) {
+  const char* env = getenv("PGCA_GEMM_RING");
+  if (env) return atoi(env);
+  (void)a;
+  return 0;  // end-to-end the plain loop is as fast as the mixed policy (820 vs 827 pairs/s): one kernel, one schedule
+}
+
 extern "C" int pgca_gemm_plan(const pgca_gemm_args* args) {
   int splits = 1;
   const int tile = plan_tile(*args, &splits);
-  return tile * 100 + (tile == 256 ? splits : 1);
+  if (tile != 256) return 12801;
+  return plan_variant(*args) * 1000000 + 25600 + splits;
 }
 
 extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
@@ -862,9 +1156,26 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       if (splits > 1) b.accumulate = 2;
       const int nkps = (nk_total + splits - 1) / splits;
       dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
-      const char* ring_env = getenv("PGCA_GEMM_RING");
-      const bool ring = ring_env ? atoi(ring_env) != 0 : false;  // measured: the 2-stage BK=64 loop is 5-10 % faster
-      if (ring) {
+      const int variant = plan_variant(a);
+      if (variant == 3) {
+        switch (a.layout) {
+          case PGCA_NT: hipLaunchKernelGGL((gemm256q_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          case PGCA_NN: hipLaunchKernelGGL((gemm256q_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          case PGCA_TN: hipLaunchKernelGGL((gemm256q_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
+        }
+        return check_launch("pgca_gemm_bf16(256 phased ring)");
+      }
+      if (variant == 2) {
+        switch (a.layout) {
+          case PGCA_NT: hipLaunchKernelGGL((gemm256p_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          case PGCA_NN: hipLaunchKernelGGL((gemm256p_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          case PGCA_TN: hipLaunchKernelGGL((gemm256p_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
+          default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
+        }
+        return check_launch("pgca_gemm_bf16(256 phased)");
+      }
+      if (variant == 1) {
         switch (a.layout) {
           case PGCA_NT: hipLaunchKernelGGL((gemm256r_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
           case PGCA_NN: hipLaunchKernelGGL((gemm256r_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
