@@ -131,11 +131,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=8)
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout of the policy (reference: 0.1)")
     args = ap.parse_args()
 
     from pgca_amd import hip
     from pgca_amd.arch import make_arch
     from pgca_amd.dist import DataParallel, OverlappedTrunkReducer
+    from pgca_amd.engine import DropoutPlan
     from pgca_amd.model import PreferenceGuidedCaptioningModel
     from pgca_amd.steps import DPOStep, FusedOptimizer, ReferencePolicy
 
@@ -154,7 +156,8 @@ def main():
                                             freeze_vision_backbone=True, device=dev, seed=42)
     ref = None if args.reference_free else ReferencePolicy(model.store, model.ws)
     step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
-                   model.caption_decoder.engine, beta=beta, reference_free=args.reference_free, ref=ref)
+                   model.caption_decoder.engine, beta=beta, reference_free=args.reference_free, ref=ref,
+                   dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
     segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
     opt = FusedOptimizer(segs, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=500,
                          total_steps=100000, sched_stride=dp.world)
@@ -219,7 +222,10 @@ def main():
                                     + f", {args.vision_model} (frozen) + {args.text_model} decoder, seq_len {S}, "
                                     "beta 0.1, bf16 MFMA / f32 accumulate+master, AdamW+clip"),
                        "pairs_per_gpu": B, "global_pairs_per_step": B * dp.world, "seq_len": S,
-                       "parallelism": f"dp{dp.world}", "dropout": "identity (p=0)"},
+                       "parallelism": f"dp{dp.world}",
+                       "dropout": (f"train mode, p={args.dropout} at the reference's sites (fused, counter-based, "
+                                   "replayed in backward); reference policy in eval mode") if args.dropout > 0
+                       else "identity (p=0)"},
             "algorithmic_gflop_per_pair": flop_pair / 1e9,
             "step_tflops_per_gpu": flop_pair * B / (dt / args.steps) / 1e12,
             "loss": loss_val, "grad_norm": st["grad_norm"], "opt_steps": st["step"],

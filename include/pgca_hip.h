@@ -91,6 +91,13 @@ typedef struct pgca_gemm_args {
   const float* row_lse;   /* [M] (DLOGITS) */
   const float* row_scale; /* [M] (DLOGITS) */
   int32_t out_cols;       /* DLOGITS: columns written (>= N, padding columns get 0) */
+  /* fused dropout on the epilogue value (after the activation / derivative, before the residual add):
+   * element (m, n) is multiplied by 0 or drop_scale according to pgca's counter hash of (drop_seed, m*N + n);
+   * drop_threshold = p * 2^32, 0 disables.  Replaces nn.Dropout at model.py:139,341,524 and GPT-2 resid_dropout
+   * (modeling_gpt2.py:224,242); the backward passes the same seed to replay the mask. */
+  uint32_t drop_seed;
+  uint32_t drop_threshold;
+  float drop_scale;
 } pgca_gemm_args;
 
 int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
@@ -118,12 +125,15 @@ int pgca_layernorm_fwd(const float* x, const int32_t* row_map, int32_t M, int32_
  * dx_bf16 (optional) receives the same value rounded to bf16 (operand of the next dgrad GEMM).
  * dgamma/dbeta partial sums go to part[2, nblk, H] (nblk returned by pgca_layernorm_bwd_blocks);
  * pgca_colsum_finish folds them into the gradient buffers.  part_extra[2, nblk, H] (optional) receives the column
- * sums of add_to and of dx_out - the bias gradients of the two GEMMs around this LayerNorm, for free. */
+ * sums of add_to and of dx_out - the bias gradients of the two GEMMs around this LayerNorm, for free.
+ * drop_add / drop_dx (HOST pointers to {seed, threshold, scale-as-float-bits}, or NULL) replay the dropout masks of
+ * those two GEMM outputs: the add_to column sum uses drop_add; dx_bf16 and the dx column sum use drop_dx (dx_out
+ * itself, the f32 residual-stream gradient, is never masked). */
 int pgca_layernorm_bwd_blocks(int32_t M);
 int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
                        int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
                        const float* add_to, float* dx_out, void* dx_bf16, float* part, float* part_extra,
-                       void* stream);
+                       const uint32_t* drop_add, const uint32_t* drop_dx, void* stream);
 /* out[h] (+)= sum_b part[b, h]; nparts rows of length H. */
 int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, float* out, int32_t accumulate, void* stream);
 
@@ -140,11 +150,13 @@ int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, in
  * softmax(q k^t / 8 + mask) v with mask = causal AND key_mask[b, key] != 0 (key_mask int32 [B,S] or NULL).
  * S <= 128.  Replaces SDPA at modeling_gpt2.py:54-72,203-215 and modeling_clip.py:259-277. */
 int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int32_t B, int32_t S, int32_t heads,
-                       int32_t causal, void* out, float* lse, void* stream);
-/* dqkv bf16 [B*S, 3*H] from dout bf16 [B*S, H], the saved qkv / out / lse. */
+                       int32_t causal, void* out, float* lse, uint32_t drop_seed, uint32_t drop_threshold,
+                       float drop_scale, void* stream);
+/* dqkv bf16 [B*S, 3*H] from dout bf16 [B*S, H], the saved qkv / out / lse.  drop_*: attention-probability
+ * dropout (element index ((b*heads + h)*S + q)*S + key; threshold 0 disables), replayed in the backward. */
 int pgca_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                        const int32_t* key_mask, int32_t B, int32_t S, int32_t heads, int32_t causal,
-                       void* dqkv, void* stream);
+                       void* dqkv, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale, void* stream);
 
 /* ------------------------------------------------------------------ embeddings */
 /* Caption-decoder input (reference model.py:591-601 + modeling_gpt2.py:571-577):
@@ -152,15 +164,22 @@ int pgca_attention_bwd(const void* qkv, const void* out, const void* dout, const
  * attended[b] = W_o(W_v pv_b + b_v) + b_o is the collapsed 1-key cross-attention.
  * Text tower (modeling_gpt2.py:568-577): attended == NULL and gamma == NULL -> h0 = wte[id] + wpe[s].
  * mean/rstd [B*S] saved when LN is applied. ids int64. */
+/* Train-mode extras (all optional): attended is read at row b*att_stride (0 = one shared vector, i.e. b_o);
+ * U [B, xheads, H] adds sum_h w(b,h,s) U[b,h,:] with w the replayable dropout multiplier of the 1-key
+ * attention weight (drop_x, index (b*xheads + h)*S + s); drop_e is GPT-2's embedding dropout on h0
+ * (index m*H + c).  drop_* are HOST pointers to {seed, threshold, scale bits} or NULL. */
 int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t H, const float* wte, const float* wpe,
                    const float* attended, const float* gamma, const float* beta, float eps, float* h0,
-                   float* mean, float* rstd, void* stream);
+                   float* mean, float* rstd, int32_t att_stride, const float* U, int32_t xheads,
+                   const uint32_t* drop_x, const uint32_t* drop_e, void* stream);
 /* Backward of the above given g = dL/dh0 [B*S, H] (f32):
  *   dwpe[s] += sum_b g; through LN (if gamma) -> de; dwte[ids] += de (rows with row_mask==0 skipped:
  *   their gradient is exactly zero); dattended[b] = sum_s de; dgamma/dbeta partials in part[2,nblk,H]. */
 int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t* row_mask, int32_t B, int32_t S, int32_t H,
                    const float* wte, const float* attended, const float* gamma, const float* mean,
-                   const float* rstd, float* dwte, float* dwpe, float* dattended, float* part, void* stream);
+                   const float* rstd, float* dwte, float* dwpe, float* dattended, float* part, int32_t att_stride,
+                   const float* U, float* dU, int32_t xheads, const uint32_t* drop_x, const uint32_t* drop_e,
+                   void* stream);
 int pgca_embed_bwd_blocks(int32_t B, int32_t S);
 
 /* ViT patch gather (modeling_clip.py:200-218): pixels f32 [B,3,I,I] -> bf16 [B*G*G, 3*P*P] in the

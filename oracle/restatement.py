@@ -30,6 +30,61 @@ import torch.nn.functional as F
 SD = Dict[str, torch.Tensor]
 
 
+# ----------------------------------------------------------------------------- dropout (train mode)
+# The reference's six nn.Dropout sites draw from torch's global Philox stream, which no other implementation can
+# reproduce bit for bit.  The MI355X path uses a counter-based mask: element `idx` of site `seed` is dropped iff
+# lowbias32(idx * 0x9E3779B1 + seed) < p * 2^32.  This restates that function so that train-mode parity (same
+# masks on both sides) is testable; with p = 0 everything below is the reference's eval-mode arithmetic.
+_M32 = 0xFFFFFFFF
+KIND_EMBD, KIND_ATTN, KIND_RESID_ATTN, KIND_RESID_MLP, KIND_VPROJ, KIND_XATTN, KIND_HEAD = range(7)
+TOWER_DECODER, TOWER_TEXT, TOWER_VHEAD, TOWER_THEAD = range(4)
+
+
+def _hash32_int(x: int) -> int:
+    x &= _M32
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & _M32
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & _M32
+    x ^= x >> 16
+    return x
+
+
+def site_seed(base_seed: int, step: int, tower: int, layer: int, kind: int) -> int:
+    return _hash32_int(_hash32_int(base_seed * 0x9E3779B1 + step) ^ ((tower << 24) | ((layer & 0xFFFF) << 8) | kind))
+
+
+def dropout_multiplier(seed: int, p: float, numel: int) -> torch.Tensor:
+    """f32 tensor of 0 / 1/(1-p) for elements 0..numel-1 of the site with this seed."""
+    x = (torch.arange(numel, dtype=torch.int64) * 0x9E3779B1 + seed) & _M32
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & _M32
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & _M32
+    x = x ^ (x >> 16)
+    keep = x >= min(_M32, int(p * 4294967296.0))
+    return keep.to(torch.float32) / (1.0 - p)
+
+
+class Dropper:
+    """mult(tower, layer, kind, shape) -> multiplier tensor (or None when p == 0)."""
+
+    def __init__(self, base_seed: int, p: float, step: int = 0):
+        self.base_seed, self.p, self.step = base_seed, p, step
+
+    def mult(self, tower: int, layer: int, kind: int, shape) -> Optional[torch.Tensor]:
+        if self.p <= 0.0:
+            return None
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return dropout_multiplier(site_seed(self.base_seed, self.step, tower, layer, kind), self.p, n).view(*shape)
+
+
+def _apply(x: torch.Tensor, m: Optional[torch.Tensor]) -> torch.Tensor:
+    return x if m is None else x * m
+
+
 # ----------------------------------------------------------------------------- primitives
 def layer_norm(x: torch.Tensor, sd: SD, prefix: str, eps: float = 1e-5) -> torch.Tensor:
     return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
@@ -55,10 +110,12 @@ def conv1d(x: torch.Tensor, sd: SD, prefix: str) -> torch.Tensor:
     return x @ sd[prefix + ".weight"] + sd[prefix + ".bias"]
 
 
-def projection_head(x: torch.Tensor, sd: SD, prefix: str) -> torch.Tensor:
-    """Linear -> ReLU -> Dropout(eval: identity) -> Linear -> LayerNorm.
-    Reference model.py:136-142 (vision) and :338-344 (text)."""
+def projection_head(x: torch.Tensor, sd: SD, prefix: str, drop: Optional[Dropper] = None,
+                    tower: int = TOWER_VHEAD) -> torch.Tensor:
+    """Linear -> ReLU -> Dropout -> Linear -> LayerNorm.  Reference model.py:136-142 (vision), :338-344 (text)."""
     h = torch.relu(linear(x, sd, prefix + ".0"))
+    if drop is not None:
+        h = _apply(h, drop.mult(tower, 0, KIND_HEAD, h.shape))
     h = linear(h, sd, prefix + ".3")
     return layer_norm(h, sd, prefix + ".4", 1e-5)
 
@@ -108,20 +165,21 @@ def vit_forward(sd: SD, prefix: str, pixel_values: torch.Tensor, heads: int, pat
     return x, pooled
 
 
-def vision_encoder_forward(sd: SD, pixel_values: torch.Tensor, heads: int, patch: int) -> Dict[str, torch.Tensor]:
+def vision_encoder_forward(sd: SD, pixel_values: torch.Tensor, heads: int, patch: int,
+                           drop: Optional[Dropper] = None) -> Dict[str, torch.Tensor]:
     """Reference ``VisionEncoder.forward`` (model.py:166-243)."""
     if pixel_values.dim() != 4:
         raise ValueError(f"Expected pixel_values to be 4D tensor (B, C, H, W), got {pixel_values.dim()}D")
     if pixel_values.size(1) != 3:
         raise ValueError(f"Expected 3 channels (RGB), got {pixel_values.size(1)} channels")
     feats, pooled = vit_forward(sd, "vision_encoder.vision_model", pixel_values, heads, patch)
-    emb = projection_head(pooled, sd, "vision_encoder.projection")
+    emb = projection_head(pooled, sd, "vision_encoder.projection", drop, TOWER_VHEAD)
     return {"features": feats, "embeddings": emb, "pooled_output": pooled}
 
 
 # ----------------------------------------------------------------------------- GPT-2 trunk
 def gpt2_trunk(sd: SD, prefix: str, hidden: torch.Tensor, attention_mask: Optional[torch.Tensor],
-               heads: int, eps: float = 1e-5) -> torch.Tensor:
+               heads: int, eps: float = 1e-5, drop: Optional[Dropper] = None, tower: int = TOWER_DECODER) -> torch.Tensor:
     """HF ``GPT2Model`` from ``inputs_embeds`` onward (modeling_gpt2.py:568-622):
     ``+ wpe(arange(S))`` irrespective of padding (:571-577), additive causal AND
     key-padding mask (:583), pre-LN blocks (:283-310) with ``gelu_new`` MLP, ``ln_f``.
@@ -131,6 +189,8 @@ def gpt2_trunk(sd: SD, prefix: str, hidden: torch.Tensor, attention_mask: Option
     b, s, hid = hidden.shape
     dh = hid // heads
     x = hidden + sd[prefix + ".wpe.weight"][:s][None]
+    if drop is not None:  # self.drop (modeling_gpt2.py:604)
+        x = _apply(x, drop.mult(tower, 0, KIND_EMBD, x.shape))
     allowed = torch.tril(torch.ones(s, s, dtype=torch.bool, device=hidden.device))[None, None]
     if attention_mask is not None:
         allowed = allowed & (attention_mask[:, None, None, :] != 0)
@@ -148,17 +208,24 @@ def gpt2_trunk(sd: SD, prefix: str, hidden: torch.Tensor, attention_mask: Option
         k = k.view(b, s, heads, dh).transpose(1, 2)
         v = v.view(b, s, heads, dh).transpose(1, 2)
         att = torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5 + bias, dim=-1)
+        if drop is not None:  # attn_dropout (modeling_gpt2.py:66)
+            att = _apply(att, drop.mult(tower, i, KIND_ATTN, att.shape))
         y = (att @ v).transpose(1, 2).reshape(b, s, hid)
-        x = r + conv1d(y, sd, p + ".attn.c_proj")
+        y = conv1d(y, sd, p + ".attn.c_proj")
+        if drop is not None:  # resid_dropout (modeling_gpt2.py:224)
+            y = _apply(y, drop.mult(tower, i, KIND_RESID_ATTN, y.shape))
+        x = r + y
         r = x
         y = layer_norm(x, sd, p + ".ln_2", eps)
         y = conv1d(gelu_new(conv1d(y, sd, p + ".mlp.c_fc")), sd, p + ".mlp.c_proj")
+        if drop is not None:  # mlp.dropout (modeling_gpt2.py:242)
+            y = _apply(y, drop.mult(tower, i, KIND_RESID_MLP, y.shape))
         x = r + y
     return layer_norm(x, sd, prefix + ".ln_f", eps)
 
 
 def text_encoder_forward(sd: SD, input_ids: torch.Tensor, attention_mask: torch.Tensor,
-                         heads: int) -> Dict[str, torch.Tensor]:
+                         heads: int, drop: Optional[Dropper] = None) -> Dict[str, torch.Tensor]:
     """Reference ``TextEncoder.forward`` (model.py:402-474): GPT2Model -> masked mean
     pool with ``clamp(min=1)`` divisor (:449-456) -> projection head (:463)."""
     if input_ids.dim() != 2:
@@ -169,15 +236,15 @@ def text_encoder_forward(sd: SD, input_ids: torch.Tensor, attention_mask: torch.
         raise ValueError(
             f"input_ids shape {input_ids.shape} doesn't match attention_mask shape {attention_mask.shape}")
     p = "text_encoder.text_model"
-    feats = gpt2_trunk(sd, p, sd[p + ".wte.weight"][input_ids], attention_mask, heads)
+    feats = gpt2_trunk(sd, p, sd[p + ".wte.weight"][input_ids], attention_mask, heads, drop=drop, tower=TOWER_TEXT)
     m = attention_mask.unsqueeze(-1).to(feats.dtype)
     pooled = (feats * m).sum(dim=1) / torch.clamp(attention_mask.sum(dim=1, keepdim=True), min=1)
-    emb = projection_head(pooled.float(), sd, "text_encoder.projection")
+    emb = projection_head(pooled.float(), sd, "text_encoder.projection", drop, TOWER_THEAD)
     return {"features": feats.float(), "embeddings": emb, "pooled_output": pooled.float()}
 
 
 def cross_attention_one_key(sd: SD, prefix: str, query: torch.Tensor, kv: torch.Tensor,
-                            heads: int) -> torch.Tensor:
+                            heads: int, drop: Optional[Dropper] = None) -> torch.Tensor:
     """``nn.MultiheadAttention(H, heads, batch_first=True)`` with key/value length 1
     (reference model.py:528-533,594-598), written out in full: per-head softmax over
     a single key.  ``query [B,S,H]``, ``kv [B,1,H]``.
@@ -193,27 +260,33 @@ def cross_attention_one_key(sd: SD, prefix: str, query: torch.Tensor, kv: torch.
     k = k.view(b, 1, heads, dh).transpose(1, 2)
     v = v.view(b, 1, heads, dh).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(dh), dim=-1)  # [B,heads,S,1] == 1
+    if drop is not None:  # nn.MultiheadAttention(dropout=p) drops attention WEIGHTS: each (b, head, s) is 0 or 1/(1-p)
+        att = _apply(att, drop.mult(TOWER_DECODER, 0, KIND_XATTN, att.shape))
     o = (att @ v).transpose(1, 2).reshape(b, s, h)
     return o @ sd[prefix + ".out_proj.weight"].t() + sd[prefix + ".out_proj.bias"]
 
 
 def caption_decoder_hidden(sd: SD, vision_embeddings: torch.Tensor, input_ids: torch.Tensor,
-                           attention_mask: torch.Tensor, heads: int, xattn_heads: int = 8) -> torch.Tensor:
+                           attention_mask: torch.Tensor, heads: int, xattn_heads: int = 8,
+                           drop: Optional[Dropper] = None) -> torch.Tensor:
     """Reference ``CaptionDecoder.forward`` up to ``ln_f`` (model.py:583-610):
     ``tanh(Linear(emb))`` -> 1-token cross-attention over ``wte(ids)`` -> residual +
     ``attention_norm`` -> GPT-2 trunk via ``inputs_embeds``."""
     p = "caption_decoder"
-    pv = torch.tanh(linear(vision_embeddings.float(), sd, p + ".vision_projection.0")).unsqueeze(1)
+    pv = torch.tanh(linear(vision_embeddings.float(), sd, p + ".vision_projection.0"))
+    if drop is not None:  # vision_projection Dropout (model.py:524)
+        pv = _apply(pv, drop.mult(TOWER_DECODER, 0, KIND_VPROJ, pv.shape))
+    pv = pv.unsqueeze(1)
     te = sd[p + ".lm_model.transformer.wte.weight"][input_ids].float()
-    att = cross_attention_one_key(sd, p + ".cross_attention", te, pv, xattn_heads)
+    att = cross_attention_one_key(sd, p + ".cross_attention", te, pv, xattn_heads, drop)
     te = layer_norm(te + att, sd, p + ".attention_norm", 1e-5)
-    return gpt2_trunk(sd, p + ".lm_model.transformer", te, attention_mask, heads)
+    return gpt2_trunk(sd, p + ".lm_model.transformer", te, attention_mask, heads, drop=drop, tower=TOWER_DECODER)
 
 
 def caption_decoder_logits(sd: SD, vision_embeddings: torch.Tensor, input_ids: torch.Tensor,
-                           attention_mask: torch.Tensor, heads: int) -> torch.Tensor:
+                           attention_mask: torch.Tensor, heads: int, drop: Optional[Dropper] = None) -> torch.Tensor:
     """... + tied LM head (modeling_gpt2.py:638-644,700): ``logits [B,S,V]``."""
-    h = caption_decoder_hidden(sd, vision_embeddings, input_ids, attention_mask, heads)
+    h = caption_decoder_hidden(sd, vision_embeddings, input_ids, attention_mask, heads, drop=drop)
     return h @ sd["caption_decoder.lm_model.transformer.wte.weight"].t()
 
 

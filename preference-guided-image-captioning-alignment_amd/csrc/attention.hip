@@ -56,7 +56,7 @@ __device__ __forceinline__ bool key_ok(int key, int q, int S, int causal, const 
 // ------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ kmask,
                                                           int S, int heads, int causal, bf16_t* __restrict__ out,
-                                                          float* __restrict__ lse_o) {
+                                                          float* __restrict__ lse_o, Drop drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + TILE_QKV;
@@ -132,11 +132,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     sum += __shfl_xor(sum, 32);
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     if (lane < 16 && q < S && lse_o) lse_o[((size_t)b * heads + h) * S + q] = mx + __logf(sum);
+    // attention-probability dropout (GPT-2 attn_dropout, modeling_gpt2.py:66): element (b, h, q, key)
+    const unsigned dbase = (((unsigned)b * heads + h) * S + q) * S;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
+      float pv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = acc[mi][ni][r] * inv;
+        if (drop.on()) pv[r] *= drop.mul(dbase + mi * 16 + (lane >> 4) * 4 + r);
+      }
       u32x2 pk;
-      pk[0] = pack2(acc[mi][ni][0] * inv, acc[mi][ni][1] * inv);
-      pk[1] = pack2(acc[mi][ni][2] * inv, acc[mi][ni][3] * inv);
+      pk[0] = pack2(pv[0], pv[1]);
+      pk[1] = pack2(pv[2], pv[3]);
       *reinterpret_cast<u32x2*>(Ps + q * PS + (mi * 16 + (lane >> 4) * 4) * 2) = pk;
     }
   }
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse_i,
                                                           const int* __restrict__ kmask, int S, int heads, int causal,
-                                                          bf16_t* __restrict__ dqkv) {
+                                                          bf16_t* __restrict__ dqkv, Drop drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Qs = smem;
   unsigned char* Ks = smem + TILE_QKV;
@@ -257,13 +265,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
     for (int ni = 0; ni < 2; ++ni) {
       const int q = 32 * w + ni * 16 + (lane & 15);
       const float l = lses[q], dl = dels[q];
+      const unsigned dbase = (((unsigned)b * heads + h) * S + q) * S;
       float p[4], ds[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = mi * 16 + (lane >> 4) * 4 + r;
         const bool ok = mi < ntile && q < S && key_ok(key, q, S, causal, kms);
-        p[r] = ok ? __expf(s[ni][r] * scale - l) : 0.f;
-        ds[r] = p[r] * (dp[ni][r] - dl) * scale;
+        const float pu = ok ? __expf(s[ni][r] * scale - l) : 0.f;       // undropped probability
+        const float m = drop.on() ? drop.mul(dbase + key) : 1.f;          // replayed dropout multiplier
+        ds[r] = pu * (dp[ni][r] * m - dl) * scale;                        // dP = dP_dropped * m
+        p[r] = pu * m;                                                    // dV uses the dropped probabilities
       }
       u32x2 pk, dk;
       pk[0] = pack2(p[0], p[1]);
@@ -377,26 +388,29 @@ int ensure_lds_attr() {
 }  // namespace
 
 extern "C" int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int32_t B, int32_t S, int32_t heads,
-                                  int32_t causal, void* out, float* lse, void* stream) {
+                                  int32_t causal, void* out, float* lse, uint32_t drop_seed, uint32_t drop_threshold,
+                                  float drop_scale, void* stream) {
   if (!qkv || !out || B <= 0 || S <= 0 || S > SP || heads <= 0) {
     set_error("pgca_attention_fwd: bad arguments (B=%d S=%d heads=%d; S must be <= %d)", B, S, heads, SP);
     return PGCA_ERR_INVALID;
   }
   if (ensure_lds_attr()) return PGCA_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B), dim3(256), FWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
-                     key_mask, S, heads, causal, (bf16_t*)out, lse);
+                     key_mask, S, heads, causal, (bf16_t*)out, lse, Drop{drop_seed, drop_threshold, drop_scale});
   return check_launch("pgca_attention_fwd");
 }
 
 extern "C" int pgca_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                                   const int32_t* key_mask, int32_t B, int32_t S, int32_t heads, int32_t causal,
-                                  void* dqkv, void* stream) {
+                                  void* dqkv, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale,
+                                  void* stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || S <= 0 || S > SP || heads <= 0) {
     set_error("pgca_attention_bwd: bad arguments (B=%d S=%d heads=%d; S must be <= %d)", B, S, heads, SP);
     return PGCA_ERR_INVALID;
   }
   if (ensure_lds_attr()) return PGCA_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), BWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
-                     (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, S, heads, causal, (bf16_t*)dqkv);
+                     (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, S, heads, causal, (bf16_t*)dqkv,
+                     Drop{drop_seed, drop_threshold, drop_scale});
   return check_launch("pgca_attention_bwd");
 }

@@ -61,6 +61,26 @@ __device__ __forceinline__ float dgelu_new(float x) {
 // HF QuickGELUActivation (transformers/activations.py:117-123)
 __device__ __forceinline__ float quick_gelu(float x) { return x * fast_sigmoid(1.702f * x); }
 
+// Counter-based dropout: keep(seed, idx) is a pure function of the site seed and the element's linear index, so the
+// backward replays the forward's mask without storing it.  lowbias32 integer hash; an element is dropped when
+// hash < threshold (threshold = p * 2^32).  The oracle restates the same function (oracle/restatement.py).
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
+struct Drop {
+  unsigned seed, threshold;  // threshold == 0 -> dropout disabled
+  float scale;               // 1 / (1 - p)
+  __device__ __forceinline__ bool on() const { return threshold != 0u; }
+  __device__ __forceinline__ float mul(unsigned idx) const {  // multiplier of element idx: 0 or 1/(1-p)
+    return hash32(idx * 0x9E3779B1U + seed) >= threshold ? scale : 0.f;
+  }
+};
+
 // Two transposed LDS reads -> one MFMA 16x16x32 fragment from a [k][m] (k-strided) image.
 // addr0 points at row (kbase + q), addr1 at row (kbase + 4 + q) of the 4x16 blocks (see gemm.hip).
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* addr0, const unsigned char* addr1) {

@@ -180,6 +180,11 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
   } else if (EPI == PGCA_EPI_TANH) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = fast_tanh(v[j]);
+    if (a.aux_out) {  // undropped tanh, operand of DTANH in the backward
+      bf16_t* p = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
+    }
   } else if (EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH) {
     const bf16_t* p = reinterpret_cast<const bf16_t*>(a.aux_in) + (size_t)row * a.ld_aux + col;
     float x[8];
@@ -201,6 +206,12 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       v[j] = (col + j) < a.N ? rscale * (__expf(v[j] - lse) - ((col + j) == tgt ? 1.f : 0.f)) : 0.f;
+  }
+  if (a.drop_threshold) {
+    const Drop d{a.drop_seed, a.drop_threshold, a.drop_scale};
+    const unsigned base = (unsigned)row * (unsigned)a.N + (unsigned)col;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= d.mul(base + j);
   }
   if (a.residual) {
     const float* p = a.residual + (size_t)row * a.ld_res + col;

@@ -2,6 +2,8 @@
 // HBM-bound row kernels: one 64-lane wave per row, 16-B loads, statistics in registers
 // (two-pass mean / centred variance like F.layer_norm), gamma/beta gradients reduced
 // per block in registers -> LDS -> one partial row per block (no atomics).
+#include <string.h>
+
 #include "common.h"
 
 using namespace pgca;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ add_to, float* __restrict__ dx_out,
                                                      bf16_t* __restrict__ dx_bf, float* __restrict__ part,
-                                                     float* __restrict__ part_extra) {
+                                                     float* __restrict__ part_extra, Drop drop_add, Drop drop_dx) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -182,13 +184,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         d.y = rstd * (dy[j].y - c1 - xv[j].y * c2);
         d.z = rstd * (dy[j].z - c1 - xv[j].z * c2);
         d.w = rstd * (dy[j].w - c1 - xv[j].w * c2);
+        const unsigned eidx = (unsigned)row * (unsigned)H + (unsigned)c;
         if (add_to) {
-          const float4 a = *reinterpret_cast<const float4*>(add_to + row * H + c);
+          float4 a = *reinterpret_cast<const float4*>(add_to + row * H + c);
           d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
-          if (EXTRA) { sa[j].x += a.x; sa[j].y += a.y; sa[j].z += a.z; sa[j].w += a.w; }
+          if (EXTRA) {
+            if (drop_add.on()) {  // bias gradient of the GEMM whose dropped output joined this stream
+              a.x *= drop_add.mul(eidx); a.y *= drop_add.mul(eidx + 1);
+              a.z *= drop_add.mul(eidx + 2); a.w *= drop_add.mul(eidx + 3);
+            }
+            sa[j].x += a.x; sa[j].y += a.y; sa[j].z += a.z; sa[j].w += a.w;
+          }
+        }
+        *reinterpret_cast<float4*>(dx_out + row * H + c) = d;
+        if (drop_dx.on()) {  // the bf16 copy feeds the backward of a GEMM whose output was dropped: replay its mask
+          d.x *= drop_dx.mul(eidx); d.y *= drop_dx.mul(eidx + 1);
+          d.z *= drop_dx.mul(eidx + 2); d.w *= drop_dx.mul(eidx + 3);
         }
         if (EXTRA) { sd[j].x += d.x; sd[j].y += d.y; sd[j].z += d.z; sd[j].w += d.w; }
-        *reinterpret_cast<float4*>(dx_out + row * H + c) = d;
         if (dx_bf) store_bf16x4(dx_bf + row * H + c, d);
       }
     }
@@ -202,6 +215,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// 1-key cross-attention with attention-weight dropout (nn.MultiheadAttention(dropout=p), reference model.py:528-533):
+// softmax over one key is 1, dropout turns it into w(b,h,s) in {0, 1/(1-p)} per head, so
+//   attended[b,s,:] = b_o + sum_h w(b,h,s) * U[b,h,:],   U[b,h,:] = W_o[:, head h] . v_b[head h].
+// Without dropout every w is 1 and the sum collapses to one vector per b (the `att` path).
+struct XAttn {
+  const float* U;  // [B, heads, H] or NULL
+  float* dU;       // backward only
+  int heads;
+  Drop drop;
+  __device__ __forceinline__ float w(int b, int h, int s, int S) const {
+    return drop.on() ? drop.mul(((unsigned)b * heads + h) * (unsigned)S + s) : 1.f;
+  }
+};
+
+template <int NV>
+__device__ __forceinline__ void add_head_terms(const XAttn& xa, int b, int s, int S, int H, int lane, float4 (&v)[NV]) {
+  if (!xa.U) return;
+  for (int h = 0; h < xa.heads; ++h) {
+    const float w = xa.w(b, h, s, S);
+    if (w != 0.f) {
+      float4 t[NV];
+      load_row_f32<NV>(xa.U + ((size_t)b * xa.heads + h) * H, H, lane, t);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) { v[j].x += w * t[j].x; v[j].y += w * t[j].y; v[j].z += w * t[j].z; v[j].w += w * t[j].w; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ embeddings
 template <int NV>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restrict__ ids, int B, int S, int H,
@@ -209,7 +250,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
                                                         const float* __restrict__ att, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, float eps,
                                                         float* __restrict__ h0, float* __restrict__ mean_o,
-                                                        float* __restrict__ rstd_o) {
+                                                        float* __restrict__ rstd_o, int att_stride, XAttn xa,
+                                                        Drop drop_e) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= B * S) return;
@@ -217,10 +259,11 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
   float4 v[NV], t[NV];
   load_row_f32<NV>(wte + (size_t)ids[m] * H, H, lane, v);
   if (att) {
-    load_row_f32<NV>(att + (size_t)b * H, H, lane, t);
+    load_row_f32<NV>(att + (size_t)b * att_stride, H, lane, t);
 #pragma unroll
     for (int j = 0; j < NV; ++j) { v[j].x += t[j].x; v[j].y += t[j].y; v[j].z += t[j].z; v[j].w += t[j].w; }
   }
+  add_head_terms<NV>(xa, b, s, S, H, lane, v);
   float mean = 0.f, rstd = 1.f;
   if (gamma) {
     row_stats<NV>(v, H, lane, eps, mean, rstd);
@@ -239,6 +282,10 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
         y.z = (y.z - mean) * rstd * g.z + bb.z; y.w = (y.w - mean) * rstd * g.w + bb.w;
       }
       y.x += t[j].x; y.y += t[j].y; y.z += t[j].z; y.w += t[j].w;
+      if (drop_e.on()) {  // GPT-2 embedding dropout (modeling_gpt2.py:604)
+        const unsigned e = (unsigned)m * (unsigned)H + (unsigned)c;
+        y.x *= drop_e.mul(e); y.y *= drop_e.mul(e + 1); y.z *= drop_e.mul(e + 2); y.w *= drop_e.mul(e + 3);
+      }
       *reinterpret_cast<float4*>(h0 + (size_t)m * H + c) = y;
     }
   }
@@ -258,7 +305,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                         const float* __restrict__ rstd_i, float* __restrict__ dwte,
                                                         float* __restrict__ dwpe, float* __restrict__ datt,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, int att_stride, XAttn xa,
+                                                        Drop drop_e) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -278,6 +326,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     const long long id = ids[m];
     float4 dy[NV];
     load_row_f32<NV>(g + (size_t)m * H, H, lane, dy);
+    if (drop_e.on()) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const unsigned e = (unsigned)m * (unsigned)H + (unsigned)((j * 64 + lane) * 4);
+        dy[j].x *= drop_e.mul(e); dy[j].y *= drop_e.mul(e + 1); dy[j].z *= drop_e.mul(e + 2); dy[j].w *= drop_e.mul(e + 3);
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int c = (j * 64 + lane) * 4;
@@ -287,10 +342,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
       float4 xv[NV], t[NV];
       load_row_f32<NV>(wte + (size_t)id * H, H, lane, xv);
       if (att) {
-        load_row_f32<NV>(att + (size_t)b * H, H, lane, t);
+        load_row_f32<NV>(att + (size_t)b * att_stride, H, lane, t);
 #pragma unroll
         for (int j = 0; j < NV; ++j) { xv[j].x += t[j].x; xv[j].y += t[j].y; xv[j].z += t[j].z; xv[j].w += t[j].w; }
       }
+      add_head_terms<NV>(xa, b, s, S, H, lane, xv);
       const float mean = mean_i[m], rstd = rstd_i[m];
       float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -321,6 +377,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
       if (c < H) {
         atomic_add4(dwte + (size_t)id * H + c, dy[j]);
         if (datt) atomic_add4(datt + (size_t)b * H + c, dy[j]);
+        if (xa.dU) {
+          for (int h = 0; h < xa.heads; ++h) {
+            const float w = xa.w(b, h, s, S);
+            if (w != 0.f) {
+              const float4 dw = make_float4(dy[j].x * w, dy[j].y * w, dy[j].z * w, dy[j].w * w);
+              atomic_add4(xa.dU + ((size_t)b * xa.heads + h) * H + c, dw);
+            }
+          }
+        }
       }
     }
   }
@@ -463,7 +528,7 @@ extern "C" int pgca_layernorm_bwd_blocks(int32_t M) {
 extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
                                   int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
                                   const float* add_to, float* dx_out, void* dx_bf16, float* part, float* part_extra,
-                                  void* stream) {
+                                  const uint32_t* drop_add, const uint32_t* drop_dx, void* stream) {
   if (check_h("pgca_layernorm_bwd", H)) return PGCA_ERR_INVALID;
   if ((!dy_bf16) == (!dy_f32) || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || (part_extra && !part)) {
     set_error("pgca_layernorm_bwd: bad arguments");
@@ -473,14 +538,25 @@ extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, cons
   dim3 grid(pgca_layernorm_bwd_blocks(M)), block(256);
   const int nv = nv_for(H);
   const size_t lds = (size_t)2 * 4 * nv * 256 * sizeof(float);
+  // drop_* point at {seed, threshold, float bits of scale} (host memory) or are NULL
+  auto mk = [](const uint32_t* d) {
+    Drop r{0u, 0u, 1.f};
+    if (d) {
+      r.seed = d[0];
+      r.threshold = d[1];
+      memcpy(&r.scale, &d[2], sizeof(float));
+    }
+    return r;
+  };
+  const Drop da = mk(drop_add), dd = mk(drop_dx);
   if (part_extra) {
     DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32,
                                        x, row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part,
-                                       part_extra));
+                                       part_extra, da, dd));
   } else {
     DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32,
                                        x, row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part,
-                                       part_extra));
+                                       part_extra, da, dd));
   }
   return check_launch("pgca_layernorm_bwd");
 }
@@ -527,9 +603,20 @@ extern "C" int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, in
   return check_launch("pgca_colsum");
 }
 
+static Drop drop_from_words(const uint32_t* d) {
+  Drop r{0u, 0u, 1.f};
+  if (d) {
+    r.seed = d[0];
+    r.threshold = d[1];
+    memcpy(&r.scale, &d[2], sizeof(float));
+  }
+  return r;
+}
+
 extern "C" int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t H, const float* wte, const float* wpe,
                               const float* attended, const float* gamma, const float* beta, float eps, float* h0,
-                              float* mean, float* rstd, void* stream) {
+                              float* mean, float* rstd, int32_t att_stride, const float* U, int32_t xheads,
+                              const uint32_t* drop_x, const uint32_t* drop_e, void* stream) {
   if (check_h("pgca_embed_fwd", H)) return PGCA_ERR_INVALID;
   if (!ids || !wte || !wpe || !h0 || B <= 0 || S <= 0 || (gamma && (!beta || !mean || !rstd))) {
     set_error("pgca_embed_fwd: bad arguments");
@@ -537,8 +624,10 @@ extern "C" int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t 
   }
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((B * S + 3) / 4), block(256);
+  const XAttn xa{U, nullptr, xheads, drop_from_words(drop_x)};
+  const Drop de = drop_from_words(drop_e);
   DISPATCH_NV(nv_for(H), hipLaunchKernelGGL((embed_fwd_kernel<NV>), grid, block, 0, s, (const long long*)ids, B, S, H,
-                                            wte, wpe, attended, gamma, beta, eps, h0, mean, rstd));
+                                            wte, wpe, attended, gamma, beta, eps, h0, mean, rstd, att_stride, xa, de));
   return check_launch("pgca_embed_fwd");
 }
 
@@ -547,7 +636,8 @@ extern "C" int pgca_embed_bwd_blocks(int32_t B, int32_t S) { return pgca_layerno
 extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t* row_mask, int32_t B, int32_t S,
                               int32_t H, const float* wte, const float* attended, const float* gamma,
                               const float* mean, const float* rstd, float* dwte, float* dwpe, float* dattended,
-                              float* part, void* stream) {
+                              float* part, int32_t att_stride, const float* U, float* dU, int32_t xheads,
+                              const uint32_t* drop_x, const uint32_t* drop_e, void* stream) {
   if (check_h("pgca_embed_bwd", H)) return PGCA_ERR_INVALID;
   if (!g || !ids || !dwte || !dwpe || B <= 0 || S <= 0 || (gamma && (!wte || !mean || !rstd || !part))) {
     set_error("pgca_embed_bwd: bad arguments");
@@ -557,7 +647,10 @@ extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t*
   dim3 grid(pgca_embed_bwd_blocks(B, S)), block(256);
   const int nv = nv_for(H);
   const size_t lds = (size_t)2 * 4 * nv * 256 * sizeof(float);
+  const XAttn xa{U, dU, xheads, drop_from_words(drop_x)};
+  const Drop de = drop_from_words(drop_e);
   DISPATCH_NV(nv, hipLaunchKernelGGL((embed_bwd_kernel<NV>), grid, block, lds, s, g, (const long long*)ids, row_mask, B,
-                                     S, H, wte, attended, gamma, mean, rstd, dwte, dwpe, dattended, part));
+                                     S, H, wte, attended, gamma, mean, rstd, dwte, dwpe, dattended, part, att_stride, xa,
+                                     de));
   return check_launch("pgca_embed_bwd");
 }

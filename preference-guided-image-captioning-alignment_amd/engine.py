@@ -49,6 +49,49 @@ class Workspace:
         return sum(t.numel() * t.element_size() for t in self.bufs.values())
 
 
+# ------------------------------------------------------------------------------------------ dropout plan
+KIND_EMBD, KIND_ATTN, KIND_RESID_ATTN, KIND_RESID_MLP, KIND_VPROJ, KIND_XATTN, KIND_HEAD = range(7)
+TOWER_DECODER, TOWER_TEXT, TOWER_VHEAD, TOWER_THEAD = range(4)
+_M32 = 0xFFFFFFFF
+
+
+def _hash32(x: int) -> int:
+    x &= _M32
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & _M32
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & _M32
+    x ^= x >> 16
+    return x
+
+
+class DropoutPlan:
+    """Seeds of the reference's train-mode dropout sites (reference model.py:139,341,524,531 and GPT-2's
+    embd/attn/resid dropouts, modeling_gpt2.py:66,224,242,604).  Masks are a pure function of
+    (base seed, step, tower, layer, site kind, element index), so every backward kernel replays the forward's
+    mask from the same triple instead of reading a stored one.  ``site`` returns the ``(seed, threshold,
+    scale)`` triple the kernels take, or None when dropout is off (p == 0 or eval)."""
+
+    def __init__(self, p: float = 0.0, base_seed: int = 0):
+        self.p, self.base_seed, self.step, self.active = float(p), int(base_seed), 0, True
+
+    def _site(self, step: int, tower: int, layer: int, kind: int):
+        seed = _hash32(_hash32(self.base_seed * 0x9E3779B1 + step) ^ ((tower << 24) | ((layer & 0xFFFF) << 8) | kind))
+        return hip.drop_args(seed, self.p)
+
+    def site(self, tower: int, layer: int, kind: int):
+        if not self.active or self.p <= 0.0:
+            return None
+        return self._site(self.step, tower, layer, kind)
+
+    def bind(self, tower: int):
+        """Closure over the CURRENT step: the backward of this forward replays exactly these seeds."""
+        if not self.active or self.p <= 0.0:
+            return None
+        step = self.step
+        return lambda layer, kind: self._site(step, tower, layer, kind)
+
+
 # ------------------------------------------------------------------------------------------ batches
 @dataclass
 class SeqBatch:
@@ -143,12 +186,15 @@ class GptTrunk:
     def _buf(self, name, shape, dtype, zero=False):
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
 
-    def forward(self, h0: torch.Tensor, mask: Optional[torch.Tensor], Bq: int, S: int, save: bool) -> torch.Tensor:
-        """h0 [Bq*S, H] f32 (already including positions) -> residual stream after the last block."""
+    def forward(self, h0: torch.Tensor, mask: Optional[torch.Tensor], Bq: int, S: int, save: bool,
+                drop=None) -> torch.Tensor:
+        """h0 [Bq*S, H] f32 (already including positions) -> residual stream after the last block.
+        ``drop(layer, kind)`` (optional) yields the dropout triple of a site (train mode)."""
         a, H, I = self.arch, self.arch.hidden, self.arch.inner
         M = Bq * S
         L = len(self.layers)
-        sv = {"M": M, "Bq": Bq, "S": S, "mask": mask} if save else None
+        sv = {"M": M, "Bq": Bq, "S": S, "mask": mask, "drop": drop} if save else None
+        dsite = (lambda li, kind: drop(li, kind)) if drop is not None else (lambda li, kind: None)
         h = h0
         for li, P in enumerate(self.layers):
             k = f"l{li}." if save else ""
@@ -160,9 +206,10 @@ class GptTrunk:
             hip.gemm(ln1, P["wqkv"].b, M, 3 * H, H, hip.NN, bias=P["bqkv"].w, out_bf16=qkv)
             att = self._buf(k + "att", (M, H), BF16)
             lse = self._buf(k + "lse", (Bq, a.heads, S), F32)
-            hip.attention_fwd(qkv, mask, Bq, S, a.heads, True, att, lse)
+            hip.attention_fwd(qkv, mask, Bq, S, a.heads, True, att, lse, drop=dsite(li, KIND_ATTN))
             hm = self._buf(k + "hm", (M, H), F32) if save else h
-            hip.gemm(att, P["wo"].b, M, H, H, hip.NN, bias=P["bo"].w, residual=h, out_f32=hm)
+            hip.gemm(att, P["wo"].b, M, H, H, hip.NN, bias=P["bo"].w, residual=h, out_f32=hm,
+                     drop=dsite(li, KIND_RESID_ATTN))
             ln2 = self._buf(k + "ln2", (M, H), BF16)
             m2 = self._buf(k + "m2", (M,), F32)
             r2 = self._buf(k + "r2", (M,), F32)
@@ -172,7 +219,8 @@ class GptTrunk:
             hip.gemm(ln2, P["wfc"].b, M, I, H, hip.NN, epilogue=hip.EPI_GELU_NEW, bias=P["bfc"].w, out_bf16=act,
                      aux_out=pre)
             hn = self._buf(f"l{li + 1}.hin", (M, H), F32) if save else hm
-            hip.gemm(act, P["wpr"].b, M, H, I, hip.NN, bias=P["bpr"].w, residual=hm, out_f32=hn)
+            hip.gemm(act, P["wpr"].b, M, H, I, hip.NN, bias=P["bpr"].w, residual=hm, out_f32=hn,
+                     drop=dsite(li, KIND_RESID_MLP))
             if save:
                 sv[li] = dict(hin=h, ln1=ln1, m1=m1, r1=r1, qkv=qkv, att=att, lse=lse, hm=hm, ln2=ln2, m2=m2, r2=r2,
                               act=act, pre=pre)
@@ -182,9 +230,15 @@ class GptTrunk:
             self.saved = sv
         return h
 
+    def top_drop(self):
+        """Dropout triple the producer of ``g_bf`` (the ln_f backward) must apply: last layer's mlp dropout."""
+        drop = self.saved.get("drop") if self.saved else None
+        return drop(len(self.layers) - 1, KIND_RESID_MLP) if drop is not None else None
+
     def backward(self, g: torch.Tensor, g_bf: torch.Tensor) -> torch.Tensor:
         """g / g_bf: dL/d(stream after last block) as f32 and bf16 [M, H]. Returns dL/dh0 (f32).
-        Weight/bias/LN gradients are ACCUMULATED into the segment's flat gradient buffer."""
+        Weight/bias/LN gradients are ACCUMULATED into the segment's flat gradient buffer.
+        In train mode g_bf must already carry the mask of the last layer's mlp dropout (``top_drop()``)."""
         sv = self.saved
         assert sv is not None, "forward(save=True) must precede backward"
         a, H, I = self.arch, self.arch.hidden, self.arch.inner
@@ -193,6 +247,8 @@ class GptTrunk:
         nb = hip.layernorm_bwd_blocks(M)
         part4 = ws.get("ln_part", (4, nb, H), F32)   # planes: dgamma, dbeta, sum(add_to), sum(dx_out)
         part, partx = part4[:2], part4[2:]
+        drop = sv.get("drop")
+        dsite = (lambda li, kind: drop(li, kind)) if drop is not None else (lambda li, kind: None)
         for li in range(len(self.layers) - 1, -1, -1):
             P, s = self.layers[li], sv[li]
             # ---- MLP: h_out = hm + c_proj(gelu(c_fc(ln2(hm))))
@@ -206,7 +262,8 @@ class GptTrunk:
             g2 = self._buf("g_b" if (li & 1) else "g_a", (M, H), F32)
             g2_bf = self._buf("gbf_b" if (li & 1) else "gbf_a", (M, H), BF16)
             hip.layernorm_bwd(s["hm"], M, H, P["ln2w"].w, s["m2"], s["r2"], g2, dy_bf16=dln, add_to=g, dx_bf16=g2_bf,
-                              part=part, part_extra=partx)
+                              part=part, part_extra=partx, drop_add=dsite(li, KIND_RESID_MLP),
+                              drop_dx=dsite(li, KIND_RESID_ATTN))
             # the same pass summed g (bias gradient of mlp.c_proj) and g2 (bias gradient of attn.c_proj)
             _ln_param_grads(part4, nb, H, P["ln2w"].g, P["ln2b"].g, P["bpr"].g, P["bo"].g)
             # ---- attention: hm = hin + c_proj(attn(c_attn(ln1(hin))))
@@ -214,14 +271,16 @@ class GptTrunk:
             hip.gemm(g2_bf, P["wo"].b, M, H, H, hip.NT, out_bf16=datt)
             hip.gemm(s["att"], g2_bf, H, H, M, hip.TN, lda=H, ldb=H, out_f32=P["wo"].g, accumulate=True)
             dqkv = self._buf("dqkv", (M, 3 * H), BF16)
-            hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], Bq, S, a.heads, True, dqkv)
+            hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], Bq, S, a.heads, True, dqkv,
+                              drop=dsite(li, KIND_ATTN))
             hip.gemm(dqkv, P["wqkv"].b, M, H, 3 * H, hip.NT, out_bf16=dln)
             hip.gemm(s["ln1"], dqkv, H, 3 * H, M, hip.TN, lda=H, ldb=3 * H, out_f32=P["wqkv"].g, accumulate=True)
             _bias_grad(ws, M, 3 * H, 3 * H, P["bqkv"].g, x_bf16=dqkv)
             g3 = self._buf("g_c" if (li & 1) else "g_d", (M, H), F32)
             g3_bf = self._buf("gbf_c" if (li & 1) else "gbf_d", (M, H), BF16)
             hip.layernorm_bwd(s["hin"], M, H, P["ln1w"].w, s["m1"], s["r1"], g3, dy_bf16=dln, add_to=g2,
-                              dx_bf16=g3_bf, part=part)
+                              dx_bf16=g3_bf, part=part,
+                              drop_dx=dsite(li - 1, KIND_RESID_MLP) if li > 0 else None)
             _ln_param_grads(part, nb, H, P["ln1w"].g, P["ln1b"].g)
             g, g_bf = g3, g3_bf
             if self.grad_hook is not None:
@@ -241,18 +300,19 @@ class ProjHead:
         self.lnw, self.lnb = _P(seg, prefix + ".4.weight"), _P(seg, prefix + ".4.bias")
         self.saved = None
 
-    def forward(self, x_bf: torch.Tensor, B: int, save: bool) -> torch.Tensor:
-        """x_bf [B, in] bf16 -> embeddings [B, P] f32 (un-normalised)."""
+    def forward(self, x_bf: torch.Tensor, B: int, save: bool, drop=None) -> torch.Tensor:
+        """x_bf [B, in] bf16 -> embeddings [B, P] f32 (un-normalised).  ``drop``: triple of the head's Dropout."""
         ws, t, Pd = self.ws, self.tag, self.P
         h1 = ws.get(t + ".h1", (B, Pd), BF16)
-        hip.gemm(x_bf, self.w0.b, B, Pd, self.inn, hip.NT, epilogue=hip.EPI_RELU, bias=self.b0.w, out_bf16=h1)
+        hip.gemm(x_bf, self.w0.b, B, Pd, self.inn, hip.NT, epilogue=hip.EPI_RELU, bias=self.b0.w, out_bf16=h1,
+                 drop=drop)
         h2 = ws.get(t + ".h2", (B, Pd), F32)
         hip.gemm(h1, self.w3.b, B, Pd, Pd, hip.NT, bias=self.b3.w, out_f32=h2)
         emb = ws.get(t + ".emb", (B, Pd), F32)
         mean, rstd = ws.get(t + ".mean", (B,), F32), ws.get(t + ".rstd", (B,), F32)
         hip.layernorm_fwd(h2, B, Pd, self.lnw.w, self.lnb.w, 1e-5, y_f32=emb, mean=mean, rstd=rstd)
         if save:
-            self.saved = dict(x=x_bf, h1=h1, h2=h2, mean=mean, rstd=rstd, B=B)
+            self.saved = dict(x=x_bf, h1=h1, h2=h2, mean=mean, rstd=rstd, B=B, drop=drop)
         return emb
 
     def backward(self, demb: torch.Tensor, need_dx: bool) -> Optional[torch.Tensor]:
@@ -268,7 +328,8 @@ class ProjHead:
         hip.gemm(dh2_bf, s["h1"], Pd, Pd, B, hip.TN, lda=Pd, ldb=Pd, out_f32=self.w3.g, accumulate=True)
         _bias_grad(ws, B, Pd, Pd, self.b3.g, x_f32=dh2)
         dh1 = ws.get(t + ".dh1", (B, Pd), BF16)
-        hip.gemm(dh2_bf, self.w3.b, B, Pd, Pd, hip.NN, epilogue=hip.EPI_DRELU, aux_in=s["h1"], out_bf16=dh1)
+        hip.gemm(dh2_bf, self.w3.b, B, Pd, Pd, hip.NN, epilogue=hip.EPI_DRELU, aux_in=s["h1"], out_bf16=dh1,
+                 drop=s["drop"])
         hip.gemm(dh1, s["x"], Pd, self.inn, B, hip.TN, lda=Pd, ldb=self.inn, out_f32=self.w0.g, accumulate=True)
         _bias_grad(ws, B, Pd, Pd, self.b0.g, x_bf16=dh1)
         if not need_dx:
@@ -380,32 +441,50 @@ class CaptionDecoderEngine:
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
 
     # -- forward --------------------------------------------------------------------------------
-    def _prefix(self, emb: torch.Tensor, Bq: int):
-        """emb [Bq, P] f32 -> attended [Bq, H] f32 (+ saved intermediates)."""
-        H, Pd = self.arch.gpt.hidden, self.arch.proj_dim
+    def _prefix(self, emb: torch.Tensor, Bq: int, drop=None):
+        """emb [Bq, P] f32 -> the cross-attention term of the decoder input (+ saved intermediates).
+
+        Eval / p = 0: one collapsed vector per sequence, ``attended [Bq, H]``.  Train mode: the attention-weight
+        dropout of nn.MultiheadAttention makes the term per (sequence, head, position), so the per-head vectors
+        ``U [Bq, 8, H]`` are produced instead and the embedding kernel applies the replayable head weights."""
+        H, Pd, XH = self.arch.gpt.hidden, self.arch.proj_dim, self.arch.xattn_heads
+        dh = H // XH
         emb_bf = self._buf("emb_bf", (Bq, Pd), BF16)
         hip.cast_bf16(emb, emb_bf, Bq * Pd)
         pv = self._buf("pv", (Bq, H), BF16)
-        hip.gemm(emb_bf, self.vp_w.b, Bq, H, Pd, hip.NT, epilogue=hip.EPI_TANH, bias=self.vp_b.w, out_bf16=pv)
+        pv_raw = self._buf("pv_raw", (Bq, H), BF16) if drop is not None else None
+        hip.gemm(emb_bf, self.vp_w.b, Bq, H, Pd, hip.NT, epilogue=hip.EPI_TANH, bias=self.vp_b.w, out_bf16=pv,
+                 aux_out=pv_raw, drop=drop(0, KIND_VPROJ) if drop is not None else None)
         vv = self._buf("vv", (Bq, H), BF16)
         hip.gemm(pv, self.inw.b[2 * H:], Bq, H, H, hip.NT, bias=self.inb.w[2 * H:], out_bf16=vv)
-        att = self._buf("attended", (Bq, H), F32)
-        hip.gemm(vv, self.ow.b, Bq, H, H, hip.NT, bias=self.ob.w, out_f32=att)
-        return emb_bf, pv, vv, att
+        if drop is None:
+            att = self._buf("attended", (Bq, H), F32)
+            hip.gemm(vv, self.ow.b, Bq, H, H, hip.NT, bias=self.ob.w, out_f32=att)
+            return dict(emb_bf=emb_bf, pv=pv, pv_raw=pv, vv=vv, att=att, U=None)
+        U = self._buf("U", (Bq, XH, H), F32)
+        for h in range(XH):  # U[:, h, :] = vv[:, head h] @ W_o[:, head h]^t
+            hip.gemm(vv[:, h * dh:], self.ow.b[:, h * dh:], Bq, H, dh, hip.NT, lda=H, ldb=H, out_f32=U[:, h],
+                     ld_out_f32=XH * H)
+        return dict(emb_bf=emb_bf, pv=pv, pv_raw=pv_raw, vv=vv, att=None, U=U)
 
-    def hidden(self, emb: torch.Tensor, sb: SeqBatch, save: bool) -> torch.Tensor:
-        """Residual stream after the last block, [Bq*S, H] f32."""
+    def hidden(self, emb: torch.Tensor, sb: SeqBatch, save: bool, drop=None) -> torch.Tensor:
+        """Residual stream after the last block, [Bq*S, H] f32.  ``drop(layer, kind)``: train-mode dropout sites."""
         a = self.arch.gpt
-        H, Bq, S = a.hidden, sb.Bq, sb.S
+        H, Bq, S, XH = a.hidden, sb.Bq, sb.S, self.arch.xattn_heads
         M = Bq * S
-        emb_bf, pv, vv, att = self._prefix(emb, Bq)
+        pf = self._prefix(emb, Bq, drop)
         h0 = self._buf("h0", (M, H), F32)
         m0, r0 = self._buf("m0", (M,), F32), self._buf("r0", (M,), F32)
-        hip.embed_fwd(sb.ids, Bq, S, H, self.wte.w, self.wpe.w, h0, attended=att, gamma=self.anw.w, beta=self.anb.w,
-                      eps=1e-5, mean=m0, rstd=r0)
-        hL = self.trunk.forward(h0, sb.mask, Bq, S, save)
+        if drop is None:
+            hip.embed_fwd(sb.ids, Bq, S, H, self.wte.w, self.wpe.w, h0, attended=pf["att"], gamma=self.anw.w,
+                          beta=self.anb.w, eps=1e-5, mean=m0, rstd=r0)
+        else:
+            hip.embed_fwd(sb.ids, Bq, S, H, self.wte.w, self.wpe.w, h0, attended=self.ob.w, att_stride=0,
+                          gamma=self.anw.w, beta=self.anb.w, eps=1e-5, mean=m0, rstd=r0, U=pf["U"], xheads=XH,
+                          drop_x=drop(0, KIND_XATTN), drop_e=drop(0, KIND_EMBD))
+        hL = self.trunk.forward(h0, sb.mask, Bq, S, save, drop)
         if save:
-            self.saved = dict(sb=sb, emb_bf=emb_bf, pv=pv, vv=vv, att=att, m0=m0, r0=r0, hL=hL)
+            self.saved = dict(sb=sb, m0=m0, r0=r0, hL=hL, drop=drop, **pf)
         return hL
 
     def token_logprobs(self, hL: torch.Tensor, sb: SeqBatch, save: bool) -> torch.Tensor:
@@ -429,9 +508,9 @@ class CaptionDecoderEngine:
             self.saved.update(hf=hf, mf=mf, rf=rf, lse=lse)
         return tok
 
-    def sequence_logprobs(self, emb: torch.Tensor, sb: SeqBatch, reduce: str, save: bool) -> torch.Tensor:
+    def sequence_logprobs(self, emb: torch.Tensor, sb: SeqBatch, reduce: str, save: bool, drop=None) -> torch.Tensor:
         """seq_lp [Bq]: 'sum' (components.py:357-362) or 'mean' (model.py:1082-1083)."""
-        hL = self.hidden(emb, sb, save)
+        hL = self.hidden(emb, sb, save, drop)
         tok = self.token_logprobs(hL, sb, save)
         out = self._buf("seq_lp", (sb.Bq,), F32)
         hip.seq_reduce(tok, sb.seq_of_row, sb.n_rows, sb.Bq, sb.counts, 1 if reduce == "mean" else 0, out)
@@ -482,28 +561,47 @@ class CaptionDecoderEngine:
         nb = hip.layernorm_bwd_blocks(Mc)
         part = ws.get("ln_part_f", (2, nb, H), F32)
         hip.layernorm_bwd(s["hL"], Mc, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dhf, row_map=sb.row_map,
-                          dx_bf16=g_bf, part=part)
+                          dx_bf16=g_bf, part=part, drop_dx=self.trunk.top_drop())
         _ln_param_grads(part, nb, H, self.trunk.lnf_w.g, self.trunk.lnf_b.g)
         g0 = self.trunk.backward(g, g_bf)
-        # embedding + attention_norm + collapsed cross-attention
+        # embedding + attention_norm + 1-key cross-attention
+        drop = s["drop"]
+        XH = self.arch.xattn_heads
+        dh = H // XH
         datt = self._buf("datt", (Bq, H), F32, zero=True)
         nbe = hip.embed_bwd_blocks(Bq, S)
         parte = ws.get("ln_part_e", (2, nbe, H), F32)
-        hip.embed_bwd(g0, sb.ids, sb.mask, Bq, S, H, self.wte.g, self.wpe.g, wte=self.wte.w, attended=s["att"],
-                      gamma=self.anw.w, mean=s["m0"], rstd=s["r0"], dattended=datt, part=parte)
-        _ln_param_grads(parte, nbe, H, self.anw.g, self.anb.g)
-        datt_bf = self._buf("datt_bf", (Bq, H), BF16)
-        hip.cast_bf16(datt, datt_bf, Bq * H)
-        # attended = vv W_o^t + b_o
-        hip.gemm(datt_bf, s["vv"], H, H, Bq, hip.TN, lda=H, ldb=H, out_f32=self.ow.g, accumulate=True)
-        _bias_grad(ws, Bq, H, H, self.ob.g, x_f32=datt)
         dvv = self._buf("dvv", (Bq, H), BF16)
-        hip.gemm(datt_bf, self.ow.b, Bq, H, H, hip.NN, out_bf16=dvv)
+        if drop is None:
+            hip.embed_bwd(g0, sb.ids, sb.mask, Bq, S, H, self.wte.g, self.wpe.g, wte=self.wte.w, attended=s["att"],
+                          gamma=self.anw.w, mean=s["m0"], rstd=s["r0"], dattended=datt, part=parte)
+            _ln_param_grads(parte, nbe, H, self.anw.g, self.anb.g)
+            datt_bf = self._buf("datt_bf", (Bq, H), BF16)
+            hip.cast_bf16(datt, datt_bf, Bq * H)
+            # attended = vv W_o^t + b_o
+            hip.gemm(datt_bf, s["vv"], H, H, Bq, hip.TN, lda=H, ldb=H, out_f32=self.ow.g, accumulate=True)
+            _bias_grad(ws, Bq, H, H, self.ob.g, x_f32=datt)
+            hip.gemm(datt_bf, self.ow.b, Bq, H, H, hip.NN, out_bf16=dvv)
+        else:
+            dU = self._buf("dU", (Bq, XH, H), F32, zero=True)
+            hip.embed_bwd(g0, sb.ids, sb.mask, Bq, S, H, self.wte.g, self.wpe.g, wte=self.wte.w, attended=self.ob.w,
+                          att_stride=0, gamma=self.anw.w, mean=s["m0"], rstd=s["r0"], dattended=datt, part=parte,
+                          U=s["U"], dU=dU, xheads=XH, drop_x=drop(0, KIND_XATTN), drop_e=drop(0, KIND_EMBD))
+            _ln_param_grads(parte, nbe, H, self.anw.g, self.anb.g)
+            _bias_grad(ws, Bq, H, H, self.ob.g, x_f32=datt)        # d b_o = sum over rows of d e
+            dU_bf = self._buf("dU_bf", (Bq, XH, H), BF16)
+            hip.cast_bf16(dU, dU_bf, Bq * XH * H)
+            for h in range(XH):  # U[:, h] = vv[:, head h] W_o[:, head h]^t
+                hip.gemm(dU_bf[:, h], s["vv"][:, h * dh:], H, dh, Bq, hip.TN, lda=XH * H, ldb=H,
+                         out_f32=self.ow.g[:, h * dh:], ld_out_f32=H, accumulate=True)
+                hip.gemm(dU_bf[:, h], self.ow.b[:, h * dh:], Bq, dh, H, hip.NN, lda=XH * H, ldb=H,
+                         out_bf16=dvv[:, h * dh:], ld_out_bf16=H)
         # vv = pv W_v^t + b_v   (value rows of in_proj; q/k rows keep zero gradient)
         hip.gemm(dvv, s["pv"], H, H, Bq, hip.TN, lda=H, ldb=H, out_f32=self.inw.g[2 * H:], accumulate=True)
         _bias_grad(ws, Bq, H, H, self.inb.g[2 * H:], x_bf16=dvv)
         dpv = self._buf("dpv", (Bq, H), BF16)
-        hip.gemm(dvv, self.inw.b[2 * H:], Bq, H, H, hip.NN, epilogue=hip.EPI_DTANH, aux_in=s["pv"], out_bf16=dpv)
+        hip.gemm(dvv, self.inw.b[2 * H:], Bq, H, H, hip.NN, epilogue=hip.EPI_DTANH, aux_in=s["pv_raw"], out_bf16=dpv,
+                 drop=drop(0, KIND_VPROJ) if drop is not None else None)
         # pv = tanh(emb W_vp^t + b_vp)
         hip.gemm(dpv, s["emb_bf"], H, Pd, Bq, hip.TN, lda=H, ldb=Pd, out_f32=self.vp_w.g, accumulate=True)
         _bias_grad(ws, Bq, H, H, self.vp_b.g, x_bf16=dpv)
@@ -529,14 +627,14 @@ class TextTowerEngine:
     def _buf(self, name, shape, dtype, zero=False):
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
 
-    def forward(self, ids: torch.Tensor, mask: torch.Tensor, save: bool):
+    def forward(self, ids: torch.Tensor, mask: torch.Tensor, save: bool, drop=None, head_drop=None):
         """ids int64 [B,S], mask int32 [B,S] (device) -> (features [B,S,H] f32, pooled [B,H] f32, emb [B,P] f32)."""
         a = self.arch.gpt
         B, S = ids.shape
         H, M = a.hidden, B * S
         h0 = self._buf("h0", (M, H), F32)
-        hip.embed_fwd(ids, B, S, H, self.wte.w, self.wpe.w, h0)
-        hL = self.trunk.forward(h0, mask, B, S, save)
+        hip.embed_fwd(ids, B, S, H, self.wte.w, self.wpe.w, h0, drop_e=drop(0, KIND_EMBD) if drop is not None else None)
+        hL = self.trunk.forward(h0, mask, B, S, save, drop)
         feats = self._buf("feats", (M, H), F32)
         mf, rf = self._buf("mf", (M,), F32), self._buf("rf", (M,), F32)
         hip.layernorm_fwd(hL, M, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_f32=feats, mean=mf, rstd=rf)
@@ -544,9 +642,9 @@ class TextTowerEngine:
         hip.masked_mean_fwd(feats, mask, B, S, H, pooled)
         pooled_bf = self._buf("pooled_bf", (B, H), BF16)
         hip.cast_bf16(pooled, pooled_bf, B * H)
-        emb = self.head.forward(pooled_bf, B, save)
+        emb = self.head.forward(pooled_bf, B, save, head_drop)
         if save:
-            self.saved = dict(ids=ids, mask=mask, hL=hL, mf=mf, rf=rf, B=B, S=S)
+            self.saved = dict(ids=ids, mask=mask, hL=hL, mf=mf, rf=rf, B=B, S=S, drop=drop)
         return feats.view(B, S, H), pooled, emb
 
     def backward(self, demb: torch.Tensor) -> None:
@@ -560,10 +658,13 @@ class TextTowerEngine:
         g_bf = self.trunk._buf("gbf_top", (M, H), BF16)
         nb = hip.layernorm_bwd_blocks(M)
         part = ws.get("ln_part_f", (2, nb, H), F32)
-        hip.layernorm_bwd(s["hL"], M, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dfeats, dx_bf16=g_bf, part=part)
+        hip.layernorm_bwd(s["hL"], M, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dfeats, dx_bf16=g_bf, part=part,
+                          drop_dx=self.trunk.top_drop())
         _ln_param_grads(part, nb, H, self.trunk.lnf_w.g, self.trunk.lnf_b.g)
         g0 = self.trunk.backward(g, g_bf)
-        hip.embed_bwd(g0, s["ids"], s["mask"], B, S, H, self.wte.g, self.wpe.g)
+        drop = s["drop"]
+        hip.embed_bwd(g0, s["ids"], s["mask"], B, S, H, self.wte.g, self.wpe.g,
+                      drop_e=drop(0, KIND_EMBD) if drop is not None else None)
 
 
 # ------------------------------------------------------------------------------------------ NT-Xent (Stage 1 loss)

@@ -38,6 +38,7 @@ class GemmArgs(C.Structure):
         ("targets", _vp), ("stat_max", _vp), ("stat_sum", _vp), ("stat_ld", _i32),
         ("target_val", _vp), ("row_lse", _vp), ("row_scale", _vp),
         ("out_cols", _i32),
+        ("drop_seed", C.c_uint32), ("drop_threshold", C.c_uint32), ("drop_scale", _f32),
     ]
 
 
@@ -48,15 +49,17 @@ _SIGS = {
     "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_layernorm_bwd_blocks": [_i32],
-    "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pgca_colsum_finish": [_vp, _i32, _i32, _vp, _i32, _vp],
     "pgca_colsum_finish4": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "pgca_colsum_blocks": [_i32],
     "pgca_colsum": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
-    "pgca_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp],
-    "pgca_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp],
-    "pgca_embed_fwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp],
-    "pgca_embed_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pgca_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, C.c_uint32, C.c_uint32, _f32, _vp],
+    "pgca_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, C.c_uint32, C.c_uint32, _f32, _vp],
+    "pgca_embed_fwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp,
+                       _vp],
+    "pgca_embed_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
+                       _i32, _vp, _vp, _vp],
     "pgca_embed_bwd_blocks": [_i32, _i32],
     "pgca_patchify": [_vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_vit_assemble": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
@@ -123,7 +126,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
          aux_out: torch.Tensor = None, aux_in: torch.Tensor = None, ld_aux: int = None,
          targets: torch.Tensor = None, stat_max: torch.Tensor = None, stat_sum: torch.Tensor = None, stat_ld: int = 0,
          target_val: torch.Tensor = None, row_lse: torch.Tensor = None, row_scale: torch.Tensor = None,
-         out_cols: int = 0) -> None:
+         out_cols: int = 0, drop=None) -> None:
     a = GemmArgs()
     a.A, a.B = A.data_ptr(), B.data_ptr()
     a.M, a.N, a.K = M, N, K
@@ -139,6 +142,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
     a.targets, a.stat_max, a.stat_sum, a.stat_ld = _p(targets), _p(stat_max), _p(stat_sum), stat_ld
     a.target_val, a.row_lse, a.row_scale = _p(target_val), _p(row_lse), _p(row_scale)
     a.out_cols = out_cols
+    if drop is not None:
+        a.drop_seed, a.drop_threshold, a.drop_scale = drop
     probe = gemm_probe
     if probe is not None and probe.want(layout, epilogue, load().pgca_gemm_plan(C.byref(a))):
         # HIP events on the launch stream bracket this one kernel (bench.py roofline measurement)
@@ -149,6 +154,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
         probe.add(e0, e1, 2.0 * M * N * K)
         return
     _check(load().pgca_gemm_bf16(C.byref(a), _stream()), "pgca_gemm_bf16")
+
+
+def drop_args(seed: int, p: float):
+    """(seed, threshold, scale) triple understood by every kernel with fused dropout; None when p == 0."""
+    if p <= 0.0:
+        return None
+    return (seed & 0xFFFFFFFF, min(0xFFFFFFFF, int(p * 4294967296.0)), 1.0 / (1.0 - p))
 
 
 gemm_probe = None  # optional object with want(layout, epilogue, M, N, K) / add(ev0, ev1, flops)
@@ -170,10 +182,10 @@ def layernorm_bwd_blocks(M: int) -> int:
 
 
 def layernorm_bwd(x, M, H, gamma, mean, rstd, dx_out, *, dy_bf16=None, dy_f32=None, row_map=None, add_to=None,
-                  dx_bf16=None, part=None, part_extra=None):
+                  dx_bf16=None, part=None, part_extra=None, drop_add=None, drop_dx=None):
     _check(load().pgca_layernorm_bwd(_p(dy_bf16), _p(dy_f32), _p(x), _p(row_map), M, H, _p(gamma), _p(mean),
                                      _p(rstd), _p(add_to), _p(dx_out), _p(dx_bf16), _p(part), _p(part_extra),
-                                     _stream()),
+                                     _drop_words(drop_add), _drop_words(drop_dx), _stream()),
            "pgca_layernorm_bwd")
 
 
@@ -197,20 +209,36 @@ def colsum(M, N, ld, part, x_bf16=None, x_f32=None):
 
 
 # --------------------------------------------------------------------------- attention
-def attention_fwd(qkv, key_mask, B, S, heads, causal, out, lse=None):
+_NODROP = (0, 0, 1.0)
+
+
+def _drop_words(d):
+    """(seed, threshold, scale) -> host uint32[3] with the scale's float bits (NULL when dropout is off)."""
+    if d is None:
+        return None
+    import struct
+    arr = (C.c_uint32 * 3)(d[0], d[1], struct.unpack("<I", struct.pack("<f", d[2]))[0])
+    return C.cast(arr, C.c_void_p)
+
+
+def attention_fwd(qkv, key_mask, B, S, heads, causal, out, lse=None, drop=None):
+    d = drop or _NODROP
     _check(load().pgca_attention_fwd(_p(qkv), _p(key_mask), B, S, heads, 1 if causal else 0, _p(out), _p(lse),
-                                     _stream()), "pgca_attention_fwd")
+                                     d[0], d[1], d[2], _stream()), "pgca_attention_fwd")
 
 
-def attention_bwd(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv):
+def attention_bwd(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, drop=None):
+    d = drop or _NODROP
     _check(load().pgca_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(key_mask), B, S, heads,
-                                     1 if causal else 0, _p(dqkv), _stream()), "pgca_attention_bwd")
+                                     1 if causal else 0, _p(dqkv), d[0], d[1], d[2], _stream()), "pgca_attention_bwd")
 
 
 # --------------------------------------------------------------------------- embeddings / ViT input
-def embed_fwd(ids, B, S, H, wte, wpe, h0, attended=None, gamma=None, beta=None, eps=1e-5, mean=None, rstd=None):
+def embed_fwd(ids, B, S, H, wte, wpe, h0, attended=None, gamma=None, beta=None, eps=1e-5, mean=None, rstd=None,
+              att_stride=None, U=None, xheads=0, drop_x=None, drop_e=None):
     _check(load().pgca_embed_fwd(_p(ids), B, S, H, _p(wte), _p(wpe), _p(attended), _p(gamma), _p(beta), eps, _p(h0),
-                                 _p(mean), _p(rstd), _stream()), "pgca_embed_fwd")
+                                 _p(mean), _p(rstd), H if att_stride is None else att_stride, _p(U), xheads,
+                                 _drop_words(drop_x), _drop_words(drop_e), _stream()), "pgca_embed_fwd")
 
 
 def embed_bwd_blocks(B: int, S: int) -> int:
@@ -218,9 +246,11 @@ def embed_bwd_blocks(B: int, S: int) -> int:
 
 
 def embed_bwd(g, ids, row_mask, B, S, H, dwte, dwpe, wte=None, attended=None, gamma=None, mean=None, rstd=None,
-              dattended=None, part=None):
+              dattended=None, part=None, att_stride=None, U=None, dU=None, xheads=0, drop_x=None, drop_e=None):
     _check(load().pgca_embed_bwd(_p(g), _p(ids), _p(row_mask), B, S, H, _p(wte), _p(attended), _p(gamma), _p(mean),
-                                 _p(rstd), _p(dwte), _p(dwpe), _p(dattended), _p(part), _stream()), "pgca_embed_bwd")
+                                 _p(rstd), _p(dwte), _p(dwpe), _p(dattended), _p(part),
+                                 H if att_stride is None else att_stride, _p(U), _p(dU), xheads, _drop_words(drop_x),
+                                 _drop_words(drop_e), _stream()), "pgca_embed_bwd")
 
 
 def patchify(pixels, B, image, patch, out_bf16):

@@ -16,8 +16,9 @@ from typing import Dict, Iterable, List, Optional
 import torch
 
 from . import hip
-from .engine import (BF16, F32, I32, I64, CaptionDecoderEngine, NTXentEngine, ProjHead, SeqBatch, TextTowerEngine,
-                     VisionTower, Workspace, make_seq_batch)
+from .engine import (BF16, F32, I32, I64, KIND_HEAD, TOWER_DECODER, TOWER_TEXT, TOWER_THEAD, TOWER_VHEAD,
+                     CaptionDecoderEngine, DropoutPlan, NTXentEngine, ProjHead, SeqBatch, TextTowerEngine, VisionTower,
+                     Workspace, make_seq_batch)
 from .params import ParamStore, Segment
 
 
@@ -102,7 +103,7 @@ class DPOStep:
     def __init__(self, store: ParamStore, ws: Workspace, vit: VisionTower, vhead: ProjHead,
                  dec: CaptionDecoderEngine, beta: float = 0.1, reference_free: bool = False,
                  label_smoothing: float = 0.0, reduce: Optional[str] = None, ref: Optional[ReferencePolicy] = None,
-                 ref_side_stream: bool = False):
+                 ref_side_stream: bool = False, dropout: Optional[DropoutPlan] = None):
         self.store, self.ws, self.vit, self.vhead, self.dec = store, ws, vit, vhead, dec
         self.beta, self.reference_free, self.ls = float(beta), bool(reference_free), float(label_smoothing)
         # trainer parity: 2-forward == PreferenceLoss (length-mean); 4-forward == DPOPreferenceLoss (length-sum)
@@ -115,6 +116,8 @@ class DPOStep:
         self.metrics = torch.zeros(4, dtype=F32, device=dev)
         self._ref_stream = None
         self.ref_side_stream = bool(ref_side_stream)
+        # train-mode dropout of the policy (the frozen reference policy always runs without dropout)
+        self.dropout = dropout if dropout is not None else DropoutPlan(0.0)
 
     @staticmethod
     def prepare(batch: dict, device) -> dict:
@@ -129,7 +132,9 @@ class DPOStep:
         assert sb.Bq == 2 * B
         P = self.store.arch.proj_dim
         _, _, pooled_bf = self.vit.forward(images)
-        emb = self.vhead.forward(pooled_bf, B, save)
+        plan = self.dropout
+        plan.active = bool(save)          # save == training forward; evaluation forwards run without dropout
+        emb = self.vhead.forward(pooled_bf, B, save, plan.site(TOWER_VHEAD, 0, KIND_HEAD))
         emb2 = self.ws.get("dpo.emb2", (2 * B, P), F32)
         emb2[:B].copy_(emb)
         emb2[B:].copy_(emb)
@@ -151,7 +156,7 @@ class DPOStep:
                 remb2[:B].copy_(remb)
                 remb2[B:].copy_(remb)
                 ref_lp = self.ref.dec.sequence_logprobs(remb2, sb, self.reduce, False)
-        pol = self.dec.sequence_logprobs(emb2, sb, self.reduce, save)
+        pol = self.dec.sequence_logprobs(emb2, sb, self.reduce, save, plan.bind(TOWER_DECODER))
         if ref_lp is not None and self._ref_stream is not torch.cuda.current_stream():
             torch.cuda.current_stream().wait_stream(self._ref_stream)
         return pol, ref_lp
@@ -161,6 +166,7 @@ class DPOStep:
         are accumulated (loss_scale = 1/accumulation_steps, accelerate/accelerator.py:2840)."""
         B = images.shape[0]
         pol, ref_lp = self.forward(images, sb, True)
+        self.dropout.step += 1             # next micro-step draws fresh masks
         dseq = self.ws.get("dpo.dseq", (2 * B,), F32)
         hip.dpo_loss(pol[:B], pol[B:], None if ref_lp is None else ref_lp[:B], None if ref_lp is None else ref_lp[B:],
                      B, self.beta, self.ls, self.loss, dseq[:B], dseq[B:], self.metrics)
@@ -186,8 +192,9 @@ class ContrastiveStep:
     ``rank`` / ``world`` for global negatives; without it negatives are local (as the reference)."""
 
     def __init__(self, store: ParamStore, ws: Workspace, vit: VisionTower, vhead: ProjHead, text: TextTowerEngine,
-                 temperature: float, dp=None, global_negatives: bool = False):
+                 temperature: float, dp=None, global_negatives: bool = False, dropout: Optional[DropoutPlan] = None):
         self.store, self.ws, self.vit, self.vhead, self.text = store, ws, vit, vhead, text
+        self.dropout = dropout if dropout is not None else DropoutPlan(0.0)
         self.ntx = NTXentEngine(ws, store.arch.proj_dim, temperature)
         self.dp = dp if (dp is not None and global_negatives and dp.world > 1) else None
 
@@ -200,8 +207,10 @@ class ContrastiveStep:
     def forward(self, images, ids, mask, save: bool = True):
         B = images.shape[0]
         feats_v, _, pooled_bf = self.vit.forward(images)
-        iemb = self.vhead.forward(pooled_bf, B, save)
-        feats_t, _, temb = self.text.forward(ids, mask, save)
+        plan = self.dropout
+        plan.active = bool(save)
+        iemb = self.vhead.forward(pooled_bf, B, save, plan.site(TOWER_VHEAD, 0, KIND_HEAD))
+        feats_t, _, temb = self.text.forward(ids, mask, save, plan.bind(TOWER_TEXT), plan.site(TOWER_THEAD, 0, KIND_HEAD))
         img_n, in_norm = self.ntx.normalize(iemb, "i")
         txt_n, tn_norm = self.ntx.normalize(temb, "t")
         return dict(image_embeddings=img_n, text_embeddings=txt_n, vision_features=feats_v, text_features=feats_t,
@@ -210,6 +219,7 @@ class ContrastiveStep:
     def loss_and_grads(self, images, ids, mask, loss_scale: float = 1.0) -> torch.Tensor:
         B = images.shape[0]
         o = self.forward(images, ids, mask, True)
+        self.dropout.step += 1
         img_n, txt_n = o["image_embeddings"], o["text_embeddings"]
         if self.dp is None:
             loss, _, _ = self.ntx.forward(img_n, txt_n)

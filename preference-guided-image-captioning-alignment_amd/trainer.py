@@ -29,6 +29,7 @@ from typing import Any, Dict, Iterable, List, Optional
 import torch
 
 from .dist import DataParallel, OverlappedTrunkReducer
+from .engine import DropoutPlan
 from .model import PreferenceGuidedCaptioningModel
 from .steps import ContrastiveStep, DPOStep, FusedOptimizer, ReferencePolicy
 
@@ -59,6 +60,11 @@ class PreferenceGuidedTrainer:
     @property
     def is_main_process(self) -> bool:
         return self.dp.rank == 0
+
+    def _dropout_plan(self, stage: int) -> DropoutPlan:
+        """model.dropout (configs/default.yaml:22) at the reference's train-mode sites; per-rank, per-stage seed."""
+        seed = int(self.config.get("training.seed", 42)) * 1000 + stage * 100 + self.dp.rank
+        return DropoutPlan(float(getattr(self.model, "dropout", 0.0) or 0.0), base_seed=seed)
 
     # ------------------------------------------------------------------ optimiser
     def _setup_optimizer(self, stage: int, num_training_steps: int) -> FusedOptimizer:
@@ -139,7 +145,8 @@ class PreferenceGuidedTrainer:
         m = self.model
         step = ContrastiveStep(m.store, m.ws, m.vision_encoder.tower, m.vision_encoder.head, m.text_encoder.engine,
                                self.temperature, dp=self.dp,
-                               global_negatives=bool(self.config.get("mi355x.stage1.global_negatives", False)))
+                               global_negatives=bool(self.config.get("mi355x.stage1.global_negatives", False)),
+                               dropout=self._dropout_plan(1))
         reducer = OverlappedTrunkReducer(self.dp, m.text_encoder.engine.trunk,
                                          group=int(self.config.get("mi355x.allreduce_layer_group", 4)))
         extra = [s for s in opt.segments if s is not reducer.seg]
@@ -168,7 +175,8 @@ class PreferenceGuidedTrainer:
         ref = None if reference_free else ReferencePolicy(m.store, m.ws)
         step = DPOStep(m.store, m.ws, m.vision_encoder.tower, m.vision_encoder.head, m.caption_decoder.engine,
                        beta=self.beta, reference_free=reference_free,
-                       label_smoothing=float(self.config.get("mi355x.dpo.label_smoothing", 0.0)), ref=ref)
+                       label_smoothing=float(self.config.get("mi355x.dpo.label_smoothing", 0.0)), ref=ref,
+                       dropout=self._dropout_plan(2))
         reducer = OverlappedTrunkReducer(self.dp, m.caption_decoder.engine.trunk,
                                          group=int(self.config.get("mi355x.allreduce_layer_group", 4)))
         extra = [s for s in opt.segments if s is not reducer.seg]

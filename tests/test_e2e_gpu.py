@@ -228,3 +228,68 @@ def test_config2_geometry_against_oracle():
                  "vision_encoder.projection.0.weight", "vision_encoder.projection.4.weight"):
         c = cos(model.store.g(name), sd[name].grad)
         assert c >= 0.99, f"{name}: cosine {c}"
+
+
+def test_train_mode_dropout_matches_oracle_with_same_masks(tiny):
+    """Train mode (p = 0.1 at every reference dropout site): the HIP path and the oracle use the same counter-based
+    masks, so loss and gradients must agree exactly as in eval mode - including the backward's mask replay."""
+    from pgca_amd.engine import DropoutPlan
+    from pgca_amd.steps import ContrastiveStep, DPOStep
+    g, model = tiny
+    arch = model.arch
+    B = 4
+    seed, p = 4242, 0.1
+    sd = {k: v.detach().cpu().clone().requires_grad_(not k.startswith("vision_encoder.vision_model"))
+          for k, v in model.store.state_dict(aliases=False).items()}
+    img = T(g["images"])
+    ids2 = torch.cat([T(g["ids_w"]), T(g["ids_l"])])
+    mask2 = torch.cat([T(g["mask_w"]), T(g["mask_l"])])
+
+    # ---- Stage 2 (2-forward, mean log-prob), dropout step counter = 3
+    plan = DropoutPlan(p, seed)
+    plan.step = 3
+    step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                   model.caption_decoder.engine, beta=0.1, reference_free=True, dropout=plan)
+    pb = batch2(g, model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss = float(step.loss_and_grads(pb["image"], pb["seq"]))
+    assert plan.step == 4
+    drop = R.Dropper(seed, p, step=3)
+    emb = R.vision_encoder_forward(sd, img, arch.vit.heads, arch.vit.patch, drop)["embeddings"]
+    logits = R.caption_decoder_logits(sd, torch.cat([emb, emb]), ids2, mask2, arch.gpt.heads, drop)
+    lp = R.sequence_logprob_mean(logits, ids2, mask2)
+    ref = -torch.nn.functional.logsigmoid(0.1 * (lp[:B] - lp[B:])).mean()
+    ref.backward()
+    assert abs(loss - float(ref)) <= 5e-3
+    # eval-mode value differs: the masks really were applied
+    assert abs(float(step.loss_only(pb["image"], pb["seq"])) - loss) > 1e-4
+    dec = "caption_decoder.lm_model.transformer."
+    for name in (dec + "h.1.attn.c_attn.weight", dec + "h.0.attn.c_proj.weight", dec + "h.0.attn.c_proj.bias",
+                 dec + "h.1.mlp.c_proj.bias", dec + "h.0.mlp.c_fc.weight", dec + "h.0.ln_2.weight", dec + "ln_f.weight",
+                 dec + "wpe.weight", dec + "wte.weight", "caption_decoder.cross_attention.out_proj.weight",
+                 "caption_decoder.cross_attention.out_proj.bias", "caption_decoder.cross_attention.in_proj_bias",
+                 "caption_decoder.vision_projection.0.weight", "caption_decoder.attention_norm.weight",
+                 "vision_encoder.projection.0.weight", "vision_encoder.projection.3.weight"):
+        assert cos(model.store.g(name), sd[name].grad) >= 0.99, name
+    for v in sd.values():
+        v.grad = None
+
+    # ---- Stage 1, dropout step counter = 0
+    plan1 = DropoutPlan(p, seed + 1)
+    st1 = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                          model.text_encoder.engine, temperature=0.5, dropout=plan1)
+    p1 = ContrastiveStep.prepare({"image": img, "caption_ids": T(g["ids_w"]), "caption_mask": T(g["mask_w"])}, model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss1 = float(st1.loss_and_grads(p1["image"], p1["ids"], p1["mask"]))
+    drop1 = R.Dropper(seed + 1, p, step=0)
+    ie = R.vision_encoder_forward(sd, img, arch.vit.heads, arch.vit.patch, drop1)["embeddings"]
+    te = R.text_encoder_forward(sd, T(g["ids_w"]), T(g["mask_w"]), arch.gpt.heads, drop1)["embeddings"]
+    ref1 = R.nt_xent(torch.nn.functional.normalize(ie, dim=-1), torch.nn.functional.normalize(te, dim=-1), 0.5)
+    ref1.backward()
+    assert abs(loss1 - float(ref1)) <= 5e-3
+    for name in ("text_encoder.text_model.h.1.attn.c_attn.weight", "text_encoder.text_model.h.0.mlp.c_proj.weight",
+                 "text_encoder.text_model.h.0.mlp.c_proj.bias", "text_encoder.text_model.wpe.weight",
+                 "text_encoder.projection.0.weight", "vision_encoder.projection.0.weight"):
+        assert cos(model.store.g(name), sd[name].grad) >= 0.99, name

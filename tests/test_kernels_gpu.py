@@ -445,3 +445,117 @@ def test_gemm_split_k_wgrad(hip):
         hip.gemm(A, B, M, N, K, hip.TN, out_f32=out, accumulate=True)
         ref = init + a.float() @ b.float()
         close(out, ref, 3e-4, f"split-K wgrad {M}x{N}x{K}")
+
+
+# ----------------------------------------------------------------------------------------------- fused dropout
+def drop_mult(seed, p, shape):
+    """The oracle's restatement of the counter-based mask, on the device."""
+    n = int(np.prod(shape))
+    return R.dropout_multiplier(seed, p, n).view(*shape).to(dev())
+
+
+def test_dropout_hash_statistics_and_gemm_epilogue(hip, tile):
+    M, N, K = 320, 512, 128
+    a, b, A, B = operands(1, M, N, K, seed=5)
+    d = hip.drop_args(0xC0FFEE, 0.1)
+    res = rnd(M, N, seed=2)
+    out = torch.zeros(M, N, device=dev())
+    hip.gemm(A, B, M, N, K, 1, residual=res, out_f32=out, drop=d)
+    mult = drop_mult(0xC0FFEE, 0.1, (M, N))
+    ref = (a.float() @ b.float()) * mult + res
+    close(out, ref, 2e-4, "gemm + dropout + residual")
+    frac = float((mult == 0).float().mean())
+    assert abs(frac - 0.1) < 0.005 and abs(float(mult.max()) - 1 / 0.9) < 1e-6
+    # activation epilogues: dropout after the activation; DRELU / DTANH replay the same mask
+    h1 = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    hip.gemm(A, B, M, N, K, 1, epilogue=hip.EPI_RELU, out_bf16=h1, drop=d)
+    close(h1, torch.relu(a.float() @ b.float()) * mult, 1.0 / 100, "relu + dropout")
+    g = torch.zeros(M, N, dtype=torch.bfloat16, device=dev())
+    hip.gemm(A, B, M, N, K, 1, epilogue=hip.EPI_DRELU, aux_in=h1, out_bf16=g, drop=d)
+    close(g, (a.float() @ b.float()) * (h1.float() > 0) * mult, 1.0 / 100, "drelu + dropout")
+    y, yraw = torch.zeros_like(h1), torch.zeros_like(h1)
+    hip.gemm(A, B, M, N, K, 1, epilogue=hip.EPI_TANH, alpha=0.05, out_bf16=y, aux_out=yraw, drop=d)
+    th = torch.tanh(0.05 * (a.float() @ b.float()))
+    close(yraw, th, 1.0 / 100, "tanh undropped copy")
+    close(y, th * mult, 1.0 / 100, "tanh + dropout")
+
+
+def test_attention_dropout_fwd_bwd(hip):
+    B, S, heads = 3, 128, 2
+    H = heads * 64
+    qkv = rnd(B * S, 3 * H, seed=11).bfloat16()
+    lens = torch.tensor([128, 77, 16])
+    mask = (torch.arange(S)[None] < lens[:, None]).int().to(dev())
+    d = hip.drop_args(12345, 0.1)
+    out = torch.zeros(B * S, H, dtype=torch.bfloat16, device=dev())
+    lse = torch.zeros(B, heads, S, device=dev())
+    hip.attention_fwd(qkv, mask, B, S, heads, True, out, lse, drop=d)
+    mult = drop_mult(12345, 0.1, (B, heads, S, S))
+    x = qkv.float().requires_grad_()
+    q, k, v = x.view(B, S, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    allowed = torch.tril(torch.ones(S, S, dtype=torch.bool, device=dev()))[None, None] & (mask[:, None, None, :] != 0)
+    p = torch.softmax(s.masked_fill(~allowed, float("-inf")), -1) * mult
+    ref = (p @ v).permute(0, 2, 1, 3).reshape(B * S, H)
+    close(out, ref, 1.0 / 64, "attn + prob dropout")
+    valid = (mask.view(B * S, 1) != 0).float()
+    dout = (rnd(B * S, H, seed=7) * valid).bfloat16()
+    ref.backward(dout.float())
+    dqkv = torch.zeros(B * S, 3 * H, dtype=torch.bfloat16, device=dev())
+    hip.attention_bwd(qkv, out, dout, lse, mask, B, S, heads, True, dqkv, drop=d)
+    close(dqkv, x.grad, 1.0 / 40, "attn bwd with replayed dropout")
+
+
+def test_layernorm_bwd_replays_neighbour_dropout(hip):
+    M, H = 50, 256
+    x, dy, add = rnd(M, H, seed=1), rnd(M, H, seed=2), rnd(M, H, seed=3)
+    gamma = rnd(H, seed=4) * 0.1 + 1
+    mean, rstd = torch.zeros(M, device=dev()), torch.zeros(M, device=dev())
+    hip.layernorm_fwd(x, M, H, gamma, torch.zeros(H, device=dev()), y_f32=torch.zeros(M, H, device=dev()), mean=mean, rstd=rstd)
+    da, dd = hip.drop_args(111, 0.1), hip.drop_args(222, 0.1)
+    nb = hip.layernorm_bwd_blocks(M)
+    part4 = torch.zeros(4, nb, H, device=dev())
+    dx, dxb = torch.zeros(M, H, device=dev()), torch.zeros(M, H, dtype=torch.bfloat16, device=dev())
+    hip.layernorm_bwd(x, M, H, gamma, mean, rstd, dx, dy_f32=dy, add_to=add, dx_bf16=dxb, part=part4[:2],
+                      part_extra=part4[2:], drop_add=da, drop_dx=dd)
+    xs = x.clone().requires_grad_()
+    torch.nn.functional.layer_norm(xs, (H,), gamma, None, 1e-5).backward(dy)
+    want = xs.grad + add
+    close(dx, want, 2e-5, "f32 stream gradient is never masked")
+    ma, md = drop_mult(111, 0.1, (M, H)), drop_mult(222, 0.1, (M, H))
+    close(dxb, want * md, 1.0 / 100, "bf16 copy carries the consumer's mask")
+    sa, sd = torch.zeros(H, device=dev()), torch.zeros(H, device=dev())
+    hip.colsum_finish4(part4[2:], 2, nb, H, [sa, sd])
+    close(sa, (add * ma).sum(0), 2e-5, "masked column sum of add_to")
+    close(sd, (want * md).sum(0), 2e-5, "masked column sum of dx")
+
+
+def test_embed_train_mode_heads_and_dropout(hip):
+    B, S, H, V, XH = 3, 9, 128, 50, 8
+    ids = torch.randint(0, V, (B, S), generator=torch.Generator().manual_seed(0)).to(dev())
+    wte, wpe = rnd(V, H, seed=1), rnd(16, H, seed=2)
+    U, bo = rnd(B, XH, H, seed=3), rnd(H, seed=4)
+    gamma, beta = rnd(H, seed=5) * 0.1 + 1, rnd(H, seed=6) * 0.1
+    dx_, de_ = hip.drop_args(77, 0.3), hip.drop_args(88, 0.1)
+    h0 = torch.zeros(B * S, H, device=dev())
+    mean, rstd = torch.zeros(B * S, device=dev()), torch.zeros(B * S, device=dev())
+    hip.embed_fwd(ids, B, S, H, wte, wpe, h0, attended=bo, att_stride=0, gamma=gamma, beta=beta, mean=mean, rstd=rstd,
+                  U=U, xheads=XH, drop_x=dx_, drop_e=de_)
+    w = drop_mult(77, 0.3, (B, XH, S))                                  # head weights, 0 or 1/(1-p)
+    me = drop_mult(88, 0.1, (B, S, H))
+    wr, pr, Ur, br = (t.clone().requires_grad_() for t in (wte, wpe, U, bo))
+    gr, ber = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    att = br[None, None, :] + torch.einsum("bhs,bhc->bsc", w, Ur)
+    ref = (torch.nn.functional.layer_norm(wr[ids] + att, (H,), gr, ber, 1e-5) + pr[:S][None]) * me
+    close(h0, ref.view(B * S, H), 1e-5, "embed fwd (train mode)")
+    g = rnd(B * S, H, seed=9)
+    ref.view(B * S, H).backward(g)
+    dwte, dwpe, datt, dU = torch.zeros_like(wte), torch.zeros_like(wpe), torch.zeros(B, H, device=dev()), torch.zeros_like(U)
+    nb = hip.embed_bwd_blocks(B, S)
+    part = torch.zeros(2, nb, H, device=dev())
+    hip.embed_bwd(g, ids, None, B, S, H, dwte, dwpe, wte=wte, attended=bo, att_stride=0, gamma=gamma, mean=mean,
+                  rstd=rstd, dattended=datt, part=part, U=U, dU=dU, xheads=XH, drop_x=dx_, drop_e=de_)
+    close(dwte, wr.grad, 3e-5, "dwte")
+    close(dwpe, pr.grad, 3e-5, "dwpe")
+    close(dU, Ur.grad, 3e-5, "dU")
+    close(datt.sum(0), br.grad, 3e-5, "d b_o")
