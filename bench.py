@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=64)
+    ap.add_argument("--pairs-per-gpu", type=int, default=128)
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--vision-model", default="openai/clip-vit-base-patch32")
     ap.add_argument("--text-model", default="gpt2-medium")
