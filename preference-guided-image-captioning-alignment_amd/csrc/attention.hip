@@ -1,9 +1,9 @@
 // Fused multi-head self-attention for head_dim 64 and S <= 128 (GPT-2 captions: S = 128,
 // CLIP ViT-B/32: T = 50), forward and backward, on MFMA 16x16x32 bf16.
 //
-// One workgroup (4 waves) owns one (batch, head): the whole S x S score tile lives on chip,
+// One workgroup (8 waves, two per SIMD) owns one (batch, head): the whole S x S score tile lives on chip,
 // so nothing is summed across workgroups (no dQ atomics) and the scores never reach HBM.
-// Wave w owns query rows 32w..32w+31.  Scores are computed TRANSPOSED (S^t = K Q^t) so a
+// Wave w owns query rows 16w..16w+15.  Scores are computed TRANSPOSED (S^t = K Q^t) so a
 // lane holds 4 consecutive keys of one query: the softmax row-reduction is in-lane plus two
 // shuffles, and P is written to LDS with 8-byte stores.  Operands that are strided along the
 // contraction (V in P.V, and P^t / dS^t / dO / Q / K in the backward products) are read with
@@ -15,6 +15,10 @@ using namespace pgca;
 
 namespace {
 
+constexpr int NWAVE = 8;      // waves per workgroup: two per SIMD, each owning RW query (or key) rows
+constexpr int NT = 64 * NWAVE;
+constexpr int RW = 128 / NWAVE;
+constexpr int NI = RW / 16;   // 16-row MFMA tiles per wave
 constexpr int SP = 128;       // padded sequence tile
 constexpr int DH = 64;        // head dim
 constexpr int QS = 144;       // byte stride of a [.][64] bf16 row (128 + 16 pad)
@@ -25,8 +29,8 @@ constexpr int TILE_P = SP * PS;    // 34816
 // Stage a [S][64] bf16 head slice (row stride `ld` elements in global) into LDS, zero rows >= S.
 __device__ __forceinline__ void stage_head(unsigned char* lds, const bf16_t* g, int ld, int S, int t) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = t + 256 * i;  // 1024 chunks of 16 B
+  for (int i = 0; i < 1024 / NT; ++i) {
+    const int idx = t + NT * i;  // 1024 chunks of 16 B
     const int row = idx >> 3, c = idx & 7;
     u32x4 v = (u32x4){0u, 0u, 0u, 0u};
     if (row < S) v = *reinterpret_cast<const u32x4*>(g + (size_t)row * ld + c * 8);
@@ -54,7 +58,7 @@ __device__ __forceinline__ bool key_ok(int key, int q, int S, int causal, const 
 }
 
 // ------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ kmask,
+__global__ __launch_bounds__(NT, 4) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int* __restrict__ kmask,
                                                           int S, int heads, int causal, bf16_t* __restrict__ out,
                                                           float* __restrict__ lse_o, Drop drop) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -73,40 +77,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   if (t < SP) kms[t] = (t < S && (!kmask || kmask[b * S + t] != 0)) ? 1 : 0;
 
   // Q fragments straight from global: rows 32w + ni*16 + (lane&15)
-  bf16x8 fq[2][2];
+  bf16x8 fq[NI][2];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      const int q = 32 * w + ni * 16 + (lane & 15);
+      const int q = RW * w + ni * 16 + (lane & 15);
       u32x4 v = (u32x4){0u, 0u, 0u, 0u};
       if (q < S) v = *reinterpret_cast<const u32x4*>(base + (size_t)q * ld + kk * 32 + (lane >> 4) * 8);
       fq[ni][kk] = __builtin_bit_cast(bf16x8, v);
     }
   __syncthreads();
 
-  const int ntile = causal ? min(2 * w + 2, (S + 15) >> 4) : ((S + 15) >> 4);  // key tiles this wave needs
+  const int ntile = causal ? min((w + 1) * NI, (S + 15) >> 4) : ((S + 15) >> 4);  // key tiles this wave needs
   const float scale = 0.125f;
 
-  f32x4 acc[8][2];
+  f32x4 acc[8][NI];
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
-    acc[mi][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[mi][1] = acc[mi][0];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (mi < ntile) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 fk = frag_rows64(Ks, mi * 16, kk, lane);
-        acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[0][kk], acc[mi][0], 0, 0, 0);
-        acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[1][kk], acc[mi][1], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[ni][kk], acc[mi][ni], 0, 0, 0);
       }
     }
   }
 
   // softmax over keys for each query column (ni, lane&15); keys live on (mi, lane>>4, r)
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int q = 32 * w + ni * 16 + (lane & 15);
+  for (int ni = 0; ni < NI; ++ni) {
+    const int q = RW * w + ni * 16 + (lane & 15);
     float mx = -INFINITY;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi)
@@ -151,29 +156,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
   __syncthreads();
 
   // O = P V : rows 32w + mt*16.., cols nt*16.., contraction over keys in steps of 32
-  f32x4 o[2][4];
+  f32x4 o[NI][4];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) o[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nks = (ntile + 1) >> 1;
   for (int ks = 0; ks < nks; ++ks) {
-    bf16x8 fp[2], fv[4];
+    bf16x8 fp[NI], fv[4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) fp[mt] = frag_rows128(Ps, 32 * w + mt * 16, ks, lane);
+    for (int mt = 0; mt < NI; ++mt) fp[mt] = frag_rows128(Ps, RW * w + mt * 16, ks, lane);
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) fv[nt] = frag_tr(Vs, QS, ks * 32, nt * 16, lane);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         o[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fp[mt], fv[nt], o[mt][nt], 0, 0, 0);
   }
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int q = 32 * w + mt * 16 + (lane >> 4) * 4 + r;
+      const int q = RW * w + mt * 16 + (lane >> 4) * 4 + r;
       if (q < S) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------ backward
-__global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
+__global__ __launch_bounds__(NT, 2) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ O,
                                                           const bf16_t* __restrict__ dO, const float* __restrict__ lse_i,
                                                           const int* __restrict__ kmask, int S, int heads, int causal,
                                                           bf16_t* __restrict__ dqkv, Drop drop) {
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
   }
   // delta[q] = sum_d dO[q,d] * O[q,d]; thread handles chunk (row = idx>>3, c = idx&7); 8 lanes per row
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = t + 256 * i;
+  for (int i = 0; i < 1024 / NT; ++i) {
+    const int idx = t + NT * i;
     const int row = idx >> 3, c = idx & 7;
     float d = 0.f;
     if (row < S) {
@@ -233,37 +238,38 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
   __syncthreads();
 
   const int nkt = (S + 15) >> 4;
-  const int ntile = causal ? min(2 * w + 2, nkt) : nkt;
+  const int ntile = causal ? min((w + 1) * NI, nkt) : nkt;
   const float scale = 0.125f;
 
   // Phase 1: P and dS (as [q][key]) for this wave's 32 query rows.
-  bf16x8 fq[2][2], fdo[2][2];
+  bf16x8 fq[NI][2], fdo[NI][2];
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni)
+  for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      fq[ni][kk] = frag_rows64(Qs, 32 * w + ni * 16, kk, lane);
-      fdo[ni][kk] = frag_rows64(dOs, 32 * w + ni * 16, kk, lane);
+      fq[ni][kk] = frag_rows64(Qs, RW * w + ni * 16, kk, lane);
+      fdo[ni][kk] = frag_rows64(dOs, RW * w + ni * 16, kk, lane);
     }
 #pragma unroll
   for (int mi = 0; mi < 8; ++mi) {
-    f32x4 s[2], dp[2];
-    s[0] = s[1] = dp[0] = dp[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 s[NI], dp[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) s[ni] = dp[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (mi < ntile) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const bf16x8 fk = frag_rows64(Ks, mi * 16, kk, lane);
         const bf16x8 fv = frag_rows64(Vs, mi * 16, kk, lane);
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           s[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk, fq[ni][kk], s[ni], 0, 0, 0);
           dp[ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, fdo[ni][kk], dp[ni], 0, 0, 0);
         }
       }
     }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int q = 32 * w + ni * 16 + (lane & 15);
+    for (int ni = 0; ni < NI; ++ni) {
+      const int q = RW * w + ni * 16 + (lane & 15);
       const float l = lses[q], dl = dels[q];
       const unsigned dbase = (((unsigned)b * heads + h) * S + q) * S;
       float p[4], ds[4];
@@ -290,18 +296,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
 
   // Phase 2: dV = P^t dO, dK = dS^t Q for key rows 32w..32w+31; contraction over queries.
   {
-    f32x4 dv[2][4], dk[2][4];
+    f32x4 dv[NI][4], dk[NI][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) dv[mt][nt] = dk[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nqs = (S + 31) >> 5;
-    for (int qs = causal ? w : 0; qs < nqs; ++qs) {
-      bf16x8 fpt[2], fdst[2], fdo2[4], fq2[4];
+    for (int qs = causal ? ((RW * w) >> 5) : 0; qs < nqs; ++qs) {
+      bf16x8 fpt[NI], fdst[NI], fdo2[4], fq2[4];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        fpt[mt] = frag_tr(Ps, PS, qs * 32, 32 * w + mt * 16, lane);
-        fdst[mt] = frag_tr(dSs, PS, qs * 32, 32 * w + mt * 16, lane);
+      for (int mt = 0; mt < NI; ++mt) {
+        fpt[mt] = frag_tr(Ps, PS, qs * 32, RW * w + mt * 16, lane);
+        fdst[mt] = frag_tr(dSs, PS, qs * 32, RW * w + mt * 16, lane);
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
         fq2[nt] = frag_tr(Qs, QS, qs * 32, nt * 16, lane);
       }
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           dv[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fpt[mt], fdo2[nt], dv[mt][nt], 0, 0, 0);
@@ -317,10 +323,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
         }
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = 32 * w + mt * 16 + (lane >> 4) * 4 + r;
+        const int key = RW * w + mt * 16 + (lane >> 4) * 4 + r;
         if (key < S) {
           bf16_t* row = dqkv + ((size_t)b * S + key) * ld + h * DH;
 #pragma unroll
@@ -334,29 +340,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kernel(const bf16_t* __restri
 
   // Phase 3: dQ = dS K for query rows 32w..32w+31; contraction over keys.
   {
-    f32x4 dq[2][4];
+    f32x4 dq[NI][4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) dq[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nks = (ntile + 1) >> 1;
     for (int ks = 0; ks < nks; ++ks) {
-      bf16x8 fds[2], fk2[4];
+      bf16x8 fds[NI], fk2[4];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) fds[mt] = frag_rows128(dSs, 32 * w + mt * 16, ks, lane);
+      for (int mt = 0; mt < NI; ++mt) fds[mt] = frag_rows128(dSs, RW * w + mt * 16, ks, lane);
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) fk2[nt] = frag_tr(Ks, QS, ks * 32, nt * 16, lane);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
           dq[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fds[mt], fk2[nt], dq[mt][nt], 0, 0, 0);
     }
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < NI; ++mt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int q = 32 * w + mt * 16 + (lane >> 4) * 4 + r;
+        const int q = RW * w + mt * 16 + (lane >> 4) * 4 + r;
         if (q < S) {
           bf16_t* row = dqkv + ((size_t)b * S + q) * ld + h * DH;
 #pragma unroll
@@ -395,7 +401,7 @@ extern "C" int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int3
     return PGCA_ERR_INVALID;
   }
   if (ensure_lds_attr()) return PGCA_ERR_LAUNCH;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B), dim3(256), FWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B), dim3(NT), FWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
                      key_mask, S, heads, causal, (bf16_t*)out, lse, Drop{drop_seed, drop_threshold, drop_scale});
   return check_launch("pgca_attention_fwd");
 }
@@ -409,7 +415,7 @@ extern "C" int pgca_attention_bwd(const void* qkv, const void* out, const void* 
     return PGCA_ERR_INVALID;
   }
   if (ensure_lds_attr()) return PGCA_ERR_LAUNCH;
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(256), BWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(NT), BWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
                      (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, S, heads, causal, (bf16_t*)dqkv,
                      Drop{drop_seed, drop_threshold, drop_scale});
   return check_launch("pgca_attention_bwd");
