@@ -1,0 +1,93 @@
+"""Data-parallel Stage-2 step on the GPU with 2 ranks (both on cuda:0, gloo transport - the box has one GPU;
+RCCL is exercised by the driver's multi-GPU bench): all-reduced, 1/world-scaled gradients and the resulting
+AdamW update must equal the single-process step on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(n, S, vocab, seed):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(4, S + 1, (2 * n,), generator=g)
+    ids = torch.randint(0, vocab, (2 * n, S), generator=g)
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    return {"image": torch.randn(n, 3, 64, 64, generator=g), "preferred_ids": ids[:n], "rejected_ids": ids[n:],
+            "preferred_mask": mask[:n], "rejected_mask": mask[n:]}
+
+
+def _run_step(batch, dp):
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.dist import OverlappedTrunkReducer
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    from pgca_amd.steps import DPOStep, FusedOptimizer
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=tiny_arch(), seed=5, device="cuda:0")
+    step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                   model.caption_decoder.engine, beta=0.1, reference_free=True)
+    segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
+    opt = FusedOptimizer(segs, lr=1e-3, max_grad_norm=1.0, total_steps=10)
+    red = OverlappedTrunkReducer(dp, model.caption_decoder.engine.trunk, group=1) if dp else None
+    if red:
+        red.arm()
+    p = DPOStep.prepare(batch, model.device)
+    opt.zero_grad()
+    loss = float(step.loss_and_grads(p["image"], p["seq"]))
+    if red:
+        red.finish(other_segments=[segs[0]])
+    world = dp.world if dp else 1
+    grads = [s.grad.clone().cpu() / world for s in segs]
+    opt.step(grad_scale=1.0 / world)
+    torch.cuda.synchronize()
+    return loss, grads, [s.fp32.clone().cpu() for s in segs], opt.state()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgca_amd.dist import DataParallel
+        dp = DataParallel(bucket_elems=50000)
+        full = _batch(8, 16, 509, seed=77)
+        lo, hi = dp.shard(8)
+        mine = {k: v[lo:hi] for k, v in full.items()}
+        loss, grads, params, st = _run_step(mine, dp)
+        torch.save((rank, loss, grads, params, st), os.path.join(out_dir, f"rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_step(tmp_path):
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    res = [torch.load(tmp_path / f"rank{r}.pt", weights_only=False) for r in range(world)]
+    loss1, grads1, params1, st1 = _run_step(_batch(8, 16, 509, seed=77), None)
+    assert abs(0.5 * (res[0][1] + res[1][1]) - loss1) <= 1e-4            # mean of the rank losses == global mean
+    for r in range(world):
+        _, _, grads, params, st = res[r]
+        for a, b in zip(grads, grads1):
+            cosv = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
+            assert cosv >= 0.9999 and abs(float(a.norm()) / float(b.norm()) - 1) <= 1e-3
+        for a, b in zip(params, params1):                                   # same AdamW update on every rank
+            assert float((a - b).abs().max()) <= 2e-3 * 1e-3 + 1e-6 or torch.allclose(a, b, atol=2e-4)
+        assert abs(st["grad_norm"] - st1["grad_norm"]) <= 2e-3 * st1["grad_norm"] and st["step"] == 1
+    assert torch.equal(res[0][3][1], res[1][3][1])                           # replicas stay bit-identical
