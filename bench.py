@@ -145,9 +145,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
-    torch.cuda.set_device(local_rank)
-    dp = DataParallel.init_from_env("nccl")
-    dev = torch.device("cuda", local_rank)
+    # rehearsal hooks (one-GPU box): PGCA_BENCH_DEVICE pins every rank to one card, PGCA_BENCH_BACKEND=gloo
+    # swaps the transport; the driver's runs use neither (one rank per GPU over RCCL)
+    dev_index = int(os.environ.get("PGCA_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dp = DataParallel.init_from_env(os.environ.get("PGCA_BENCH_BACKEND", "nccl"))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     B, S, beta = args.pairs_per_gpu, args.seq_len, 0.1
     log(f"init: world={world} pairs/gpu={B} S={S}")
@@ -242,6 +246,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(model, arch, S, beta, args.cpu_pairs)
         print(json.dumps(res), flush=True)
     dp.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
