@@ -42,7 +42,7 @@ def _stale(target: str, deps: List[str]) -> bool:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
-    common = [os.path.join(CSRC, "common.h"), HEADER]
+    common = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [HEADER]
     cc = hipcc()
     jobs = []
     objs = []

@@ -12,300 +12,9 @@
 // (XOR-swizzled, conflict-free for both fragment read kinds), double-buffered: the next
 // tile's global loads are issued before the current tile's MFMAs and written to the other
 // LDS buffer after them (one barrier per K tile).
-#include <stdlib.h>
-
-#include "common.h"
-
-using namespace pgca;
+#include "gemm_device.h"
 
 namespace {
-
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;
-constexpr unsigned OOB = 0x80000000u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffff0, 0x00020000);
-}
-
-// ---- per-thread staging geometry of one operand tile -----------------------------------------
-// KS = 0: operand is [rows, K] (K contiguous); tile image [128 rows][64 k], 128-B rows,
-//         16-B chunk c of row r stored at chunk (c ^ (r & 7)).
-// KS = 1: operand is [K, cols] (K strided);   tile image [64 k][128 cols], 256-B rows,
-//         32-B slot s of row k stored at slot (s ^ h(k)), h(k) = (k&3) | ((k>>3)&1)<<2.
-template <int KS>
-struct Stage {
-  unsigned goff[4];   // byte offset of this thread's 4 chunks relative to the tile base pointer
-  unsigned loff[4];   // byte offset in the LDS image
-  bool vspace[4];     // row (KS=0) / column (KS=1) inside the matrix
-  int kpos[4];        // k offset inside the tile of each chunk (for the K-edge test)
-
-  __device__ __forceinline__ void init(int t, int ld, int origin, int extent) {
-    if (KS == 0) {
-      const int r = t >> 3, c = t & 7;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = r + 32 * i;
-        goff[i] = (unsigned)(row * ld + c * 8) * 2u;
-        loff[i] = (unsigned)(row * 128 + ((c ^ (row & 7)) << 4));
-        vspace[i] = (origin + row) < extent;
-        kpos[i] = c * 8;
-      }
-    } else {
-      const int kr = t >> 4, c16 = t & 15;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = kr + 16 * i;
-        const int h = (k & 3) | (((k >> 3) & 1) << 2);
-        goff[i] = (unsigned)(k * ld + c16 * 8) * 2u;
-        loff[i] = (unsigned)(k * 256 + (((c16 >> 1) ^ h) << 5) + ((c16 & 1) << 4));
-        vspace[i] = (origin + c16 * 8) < extent;
-        kpos[i] = k;
-      }
-    }
-  }
-  __device__ __forceinline__ void load(const bf16_t* base, int krem, u32x4 (&r)[4]) const {
-    __amdgpu_buffer_rsrc_t rs = make_rsrc(base);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = vspace[i] && (kpos[i] < krem);
-      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? goff[i] : OOB, 0, 0);
-    }
-  }
-  __device__ __forceinline__ void store(unsigned char* lds, const u32x4 (&r)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(lds + loff[i]) = r[i];
-  }
-};
-
-// ---- fragment readers ---------------------------------------------------------------------------
-// Returns the MFMA 16x16x32 operand fragment of 16-row (or 16-col) sub-tile `sub` of the wave's
-// 64-wide strip starting at `wbase`, k-step kk (0,1) of the 64-deep tile.
-template <int KS, int KSTRIDE = 256>
-__device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int wbase, int sub, int kk, int lane) {
-  if (KS == 0) {
-    const int row = wbase + sub * 16 + (lane & 15);
-    const int c = kk * 4 + (lane >> 4);
-    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ (lane & 7)) << 4));
-  } else {
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int k = kk * 32 + 8 * g + q;
-    const int h = q | ((g & 1) << 2);
-    const int s32 = (wbase >> 4) + sub;
-    const unsigned char* a0 = lds + k * KSTRIDE + ((s32 ^ h) << 5) + 8 * p;
-    return tr_frag(a0, a0 + 4 * KSTRIDE);
-  }
-}
-
-// ---- epilogues ------------------------------------------------------------------------------------
-// Accumulator element acc[mi][ni][r] of wave (wm, wn) is C[m0 + wm*64 + mi*16 + (lane>>4)*4 + r]
-//                                                        [n0 + wn*64 + ni*16 + (lane&15)].
-__device__ __forceinline__ void epilogue_rowstats(const pgca_gemm_args& a, f32x4 (&acc)[4][4], int m0, int n0, int tn,
-                                                  int wm, int wn, int lane) {
-  const int rbase = m0 + wm * 64 + (lane >> 4) * 4;
-  const int cbase = n0 + wn * 64 + (lane & 15);
-  const int part = (n0 >> 6) + wn;  // one partial per 64-column strip
-#pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rbase + mi * 16 + r;
-      const long long tgt = (row < a.M && a.targets) ? a.targets[row] : -1;
-      float v0, v1, v2, v3;
-      {
-        float x[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int col = cbase + ni * 16;
-          float t = a.alpha * acc[mi][ni][r];
-          if (a.bias && col < a.N) t += a.bias[col];
-          if (col == tgt && a.target_val) a.target_val[row] = t;
-          x[ni] = col < a.N ? t : -INFINITY;
-        }
-        v0 = x[0]; v1 = x[1]; v2 = x[2]; v3 = x[3];
-      }
-      float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-      float sm = 0.f;
-      if (mx > -INFINITY) sm = __expf(v0 - mx) + __expf(v1 - mx) + __expf(v2 - mx) + __expf(v3 - mx);
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
-      if ((lane & 15) == 0 && row < a.M) {
-        a.stat_max[(size_t)row * a.stat_ld + part] = mx;
-        a.stat_sum[(size_t)row * a.stat_ld + part] = sm;
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-
-// Everything that happens to 8 consecutive output columns of one row.  `nv` = number of valid columns (1..8);
-// the 16-byte vector paths are taken when nv == 8 and the row start is 16-B aligned, else element-wise.
-template <int EPI>
-__device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int col, float (&v)[8], int nv, float lse,
-                                        float rscale, long long tgt) {
-  const bool full = nv == 8;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] *= a.alpha;
-  if (a.bias) {
-    const float* bp = a.bias + col;
-    if (full && al16(bp)) {
-      const float4 b0 = *reinterpret_cast<const float4*>(bp), b1 = *reinterpret_cast<const float4*>(bp + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < nv && col + j < a.N) v[j] += bp[j];
-    }
-  }
-  if (EPI == PGCA_EPI_GELU_NEW || EPI == PGCA_EPI_QUICK_GELU) {
-    if (a.aux_out) {
-      bf16_t* p = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col;
-      if (full && al16(p)) {
-        bf16x8 t;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) t[j] = f2bf(v[j]);
-        *reinterpret_cast<bf16x8*>(p) = t;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = EPI == PGCA_EPI_GELU_NEW ? gelu_new(v[j]) : quick_gelu(v[j]);
-  } else if (EPI == PGCA_EPI_RELU) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-  } else if (EPI == PGCA_EPI_TANH) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fast_tanh(v[j]);
-    if (a.aux_out) {  // undropped tanh, operand of DTANH in the backward
-      bf16_t* p = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
-    }
-  } else if (EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH) {
-    const bf16_t* p = reinterpret_cast<const bf16_t*>(a.aux_in) + (size_t)row * a.ld_aux + col;
-    float x[8];
-    if (full && al16(p)) {
-      const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = bf2f(t[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = j < nv ? bf2f(p[j]) : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (EPI == PGCA_EPI_DGELU_NEW) v[j] *= dgelu_new(x[j]);
-      else if (EPI == PGCA_EPI_DRELU) v[j] = x[j] > 0.f ? v[j] : 0.f;
-      else v[j] *= 1.f - x[j] * x[j];
-    }
-  } else if (EPI == PGCA_EPI_DLOGITS) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      v[j] = (col + j) < a.N ? rscale * (__expf(v[j] - lse) - ((col + j) == tgt ? 1.f : 0.f)) : 0.f;
-  }
-  if (a.drop_threshold) {
-    const Drop d{a.drop_seed, a.drop_threshold, a.drop_scale};
-    const unsigned base = (unsigned)row * (unsigned)a.N + (unsigned)col;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= d.mul(base + j);
-  }
-  if (a.residual) {
-    const float* p = a.residual + (size_t)row * a.ld_res + col;
-    if (full && al16(p)) {
-      const float4 b0 = *reinterpret_cast<const float4*>(p), b1 = *reinterpret_cast<const float4*>(p + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < nv) v[j] += p[j];
-    }
-  }
-  if (a.out_f32) {
-    float* p = a.out_f32 + (size_t)row * a.ld_out_f32 + col;
-    if (full && al16(p)) {
-      float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
-      if (a.accumulate) {
-        const float4 c0 = *reinterpret_cast<const float4*>(p), c1 = *reinterpret_cast<const float4*>(p + 4);
-        o0.x += c0.x; o0.y += c0.y; o0.z += c0.z; o0.w += c0.w; o1.x += c1.x; o1.y += c1.y; o1.z += c1.z; o1.w += c1.w;
-      }
-      *reinterpret_cast<float4*>(p) = o0;
-      *reinterpret_cast<float4*>(p + 4) = o1;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < nv) p[j] = a.accumulate ? p[j] + v[j] : v[j];
-    }
-  }
-  if (a.out_bf16) {
-    bf16_t* p = reinterpret_cast<bf16_t*>(a.out_bf16) + (size_t)row * a.ld_out_bf16 + col;
-    if (full && al16(p)) {
-      bf16x8 t;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) t[j] = f2bf(v[j]);
-      *reinterpret_cast<bf16x8*>(p) = t;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
-    }
-  }
-}
-
-// The wave's 64x64 accumulator tile goes through LDS in two 32-row halves (row stride 68 floats: conflict-free
-// b32 writes in the MFMA layout, b128 reads of 8 consecutive columns), so every global access of the epilogue
-// (bias, saved activations, residual stream, outputs) is a 16-byte vector op on 128..256 contiguous bytes per row.
-template <int EPI>
-__device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int m0,
-                                               int n0, int wm, int wn, int lane, int wave) {
-  constexpr int LDC = 68;
-  float* cbuf = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
-  const int ncols = EPI == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cbuf[(mh * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = acc[half * 2 + mh][ni][r];
-    __syncthreads();
-    if (EPI == PGCA_EPI_NONE && a.accumulate == 2) {
-      // split-K partial: f32 atomic adds, one 256-byte row segment of the tile per wave-instruction
-      // (the access shape at which global_atomic_add_f32 runs at its full memory-side rate)
-      const int col = n0 + wn * 64 + lane;
-      if (col < a.N) {
-        for (int lr = 0; lr < 32; ++lr) {
-          const int row = m0 + wm * 64 + half * 32 + lr;
-          if (row < a.M) atomicAdd(a.out_f32 + (size_t)row * a.ld_out_f32 + col, a.alpha * cbuf[lr * LDC + lane]);
-        }
-      }
-    } else {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int lr = it * 8 + (lane >> 3);
-      const int row = m0 + wm * 64 + half * 32 + lr;
-      const int col = n0 + wn * 64 + (lane & 7) * 8;
-      const float4 c0 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + (lane & 7) * 8);
-      const float4 c1 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + (lane & 7) * 8 + 4);
-      if (row < a.M && col < ncols) {
-        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        float lse = 0.f, rscale = 0.f;
-        long long tgt = -1;
-        if (EPI == PGCA_EPI_DLOGITS) {
-          lse = a.row_lse[row];
-          rscale = a.row_scale[row];
-          tgt = a.targets[row];
-        }
-        const int nv = ncols - col < 8 ? ncols - col : 8;
-        finish8<EPI>(a, row, col, v, nv, lse, rscale, tgt);
-      }
-    }
-    }
-    __syncthreads();
-  }
-}
 
 template <int LA, int LB>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const pgca_gemm_args a, int ntm, int ntn) {
@@ -438,84 +147,6 @@ __global__ void rowstats_combine_kernel(const float* __restrict__ smax, const fl
 // SOURCE address (same involution as the fragment readers).  Edges: M/N by clamping the source
 // row/column (clamped rows only feed outputs the epilogue masks), K must be a multiple of 64.
 // ================================================================================================
-// Runtime epilogue selection for one 64 x 64 accumulator block whose first row is `mh` (wave column wn).
-__device__ __forceinline__ void run_epilogue(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int mh,
-                                             int n0, int tn, int wn, int lane, int wave) {
-  switch (a.epilogue) {
-    case PGCA_EPI_ROWSTATS: epilogue_rowstats(a, acc, mh, n0, tn, 0, wn, lane); break;
-    case PGCA_EPI_GELU_NEW: epilogue_store<PGCA_EPI_GELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_QUICK_GELU: epilogue_store<PGCA_EPI_QUICK_GELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_RELU: epilogue_store<PGCA_EPI_RELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_TANH: epilogue_store<PGCA_EPI_TANH>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_DGELU_NEW: epilogue_store<PGCA_EPI_DGELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_DRELU: epilogue_store<PGCA_EPI_DRELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_DTANH: epilogue_store<PGCA_EPI_DTANH>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-  }
-}
-
-constexpr int BM2 = 256, BN2 = 256;
-constexpr int TILE2_BYTES = 256 * 64 * 2;
-
-template <int KS>
-struct Dma {
-  unsigned goff[4];
-  __device__ __forceinline__ void init(int lane, int wave, int ld, int origin, int extent) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = wave * 4 + i;  // 1-KiB piece of the 32-KiB tile image
-      if (KS == 0) {               // [256 rows][64 k]: piece = 8 rows x 128 B
-        const int r = 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ (lane >> 3);
-        const int rg = min(origin + r, extent - 1) - origin;
-        goff[i] = (unsigned)(rg * ld + c * 8) * 2u;
-      } else {                     // [64 k][256 cols]: piece = 2 k-rows x 512 B
-        const int k = 2 * j + (lane >> 5);
-        const int c16 = lane & 31;
-        const int h = (k & 3) | (((k >> 3) & 1) << 2);
-        const int col = (((c16 >> 1) ^ h) << 4) + ((c16 & 1) << 3);
-        const int cg = min(origin + col, extent - 8) - origin;
-        goff[i] = (unsigned)(k * ld + cg) * 2u;
-      }
-    }
-  }
-  // The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA as a pending LDS write and
-  // drains it (s_waitcnt vmcnt(0)) in front of the next ds_read, which would serialise the copy of tile t+1 with
-  // the MFMAs of tile t.  Untracked, it stays in flight across the whole compute phase; dma_wait() retires it
-  // right before the barrier that hands the buffer to the readers.  (M0 = LDS byte address of lane 0's 16 bytes.)
-  __device__ __forceinline__ void issue(const bf16_t* base, unsigned char* tile, int wave) const {
-    const unsigned long long b = (unsigned long long)base;
-    u32x4 rs;
-    rs[0] = (unsigned)b;
-    rs[1] = (unsigned)(b >> 32) & 0xffffu;
-    rs[2] = 0x7ffffff0u;
-    rs[3] = 0x00020000u;
-    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(tile) + (unsigned)wave * 4096u;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                   :
-                   : "s"(lds0 + i * 1024u), "v"(goff[i]), "s"(rs)
-                   : "memory");
-    }
-  }
-};
-
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-template <int LA>
-__device__ __forceinline__ void mma_half(const unsigned char* la, int row0, int kk, int lane, const bf16x8 (&fb)[4],
-                                         f32x4 (&acc)[4][4]) {
-  bf16x8 fa[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa[i] = read_frag<LA, 512>(la, row0, i, kk, lane);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-}
-
 template <int LA, int LB>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [2 stages][A | B][32 KiB]
@@ -1168,6 +799,10 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       const int nkps = (nk_total + splits - 1) / splits;
       dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
       const int variant = plan_variant(a);
+      if (variant == 4) {
+        const int rc = launch_gemm256w(b, ntm2, ntn2, nkps, (int)grid2.y, stream);
+        if (rc != 1) return rc;  // 1: epilogue not implemented by the wide-wave kernel, use the 8-wave one
+      }
       if (variant == 3) {
         switch (a.layout) {
           case PGCA_NT: hipLaunchKernelGGL((gemm256q_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;

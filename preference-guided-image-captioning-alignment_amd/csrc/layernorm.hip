@@ -298,98 +298,171 @@ __device__ __forceinline__ void atomic_add4(float* p, float4 d) {
   atomicAdd(p + 3, d.w);
 }
 
-template <int NV>
+// One wave owns `chunk` consecutive positions of ONE sequence (chunk divides S), so the gradients that are shared
+// by all positions of a sequence - the attended row and the per-head U rows of the cross-attention - are summed
+// in registers and leave the wave as one atomic per chunk instead of one per row (the 128-way contended atomics
+// were 2.6 ms of the step).  The position-embedding gradient (shared ACROSS sequences) is wpe_grad_kernel's.
+// ACCU: keep the 8 per-head sums in registers (H <= 1024); wider rows fall back to per-row atomics for dU.
+template <int NV, bool ACCU>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, const long long* __restrict__ ids,
                                                         const int* __restrict__ row_mask, int B, int S, int H,
                                                         const float* __restrict__ wte, const float* __restrict__ att,
                                                         const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                         const float* __restrict__ rstd_i, float* __restrict__ dwte,
-                                                        float* __restrict__ dwpe, float* __restrict__ datt,
-                                                        float* __restrict__ part, int att_stride, XAttn xa,
-                                                        Drop drop_e) {
+                                                        float* __restrict__ datt, float* __restrict__ part,
+                                                        int att_stride, XAttn xa, Drop drop_e, int chunk) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int nw = gridDim.x * 4;
+  constexpr int NH = ACCU ? 8 : 1;
   float4 dg[NV], db[NV], gm[NV];
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    db[j] = dg[j];
+    dg[j] = zero;
+    db[j] = zero;
     const int c = (j * 64 + lane) * 4;
-    gm[j] = (gamma && c < H) ? *reinterpret_cast<const float4*>(gamma + c) : dg[j];
+    gm[j] = (gamma && c < H) ? *reinterpret_cast<const float4*>(gamma + c) : zero;
   }
-  const int M = B * S;
-  for (int m = wid; m < M; m += nw) {
-    if (row_mask && row_mask[m] == 0) continue;  // gradient of a padded position is exactly zero
-    const int b = m / S, s = m % S;
-    const long long id = ids[m];
-    float4 dy[NV];
-    load_row_f32<NV>(g + (size_t)m * H, H, lane, dy);
-    if (drop_e.on()) {
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const unsigned e = (unsigned)m * (unsigned)H + (unsigned)((j * 64 + lane) * 4);
-        dy[j].x *= drop_e.mul(e); dy[j].y *= drop_e.mul(e + 1); dy[j].z *= drop_e.mul(e + 2); dy[j].w *= drop_e.mul(e + 3);
-      }
-    }
+  const int nchunks = (B * S) / chunk;
+  for (int ch = wid; ch < nchunks; ch += nw) {
+    const int mbase = ch * chunk;
+    const int b = mbase / S;
+    float4 sa[NV], su[NH][NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int c = (j * 64 + lane) * 4;
-      if (c < H) atomic_add4(dwpe + (size_t)s * H + c, dy[j]);
-    }
-    if (gamma) {
-      float4 xv[NV], t[NV];
-      load_row_f32<NV>(wte + (size_t)id * H, H, lane, xv);
-      if (att) {
-        load_row_f32<NV>(att + (size_t)b * att_stride, H, lane, t);
+      sa[j] = zero;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { xv[j].x += t[j].x; xv[j].y += t[j].y; xv[j].z += t[j].z; xv[j].w += t[j].w; }
+      for (int h = 0; h < NH; ++h) su[h][j] = zero;
+    }
+    bool any = false;
+    for (int r = 0; r < chunk; ++r) {
+      const int m = mbase + r;
+      if (row_mask && row_mask[m] == 0) continue;  // gradient of a padded position is exactly zero
+      any = true;
+      const int s = m - b * S;
+      const long long id = ids[m];
+      float4 dy[NV];
+      load_row_f32<NV>(g + (size_t)m * H, H, lane, dy);
+      if (drop_e.on()) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const unsigned e = (unsigned)m * (unsigned)H + (unsigned)((j * 64 + lane) * 4);
+          dy[j].x *= drop_e.mul(e); dy[j].y *= drop_e.mul(e + 1); dy[j].z *= drop_e.mul(e + 2); dy[j].w *= drop_e.mul(e + 3);
+        }
       }
-      add_head_terms<NV>(xa, b, s, S, H, lane, xv);
-      const float mean = mean_i[m], rstd = rstd_i[m];
-      float c1 = 0.f, c2 = 0.f;
+      if (gamma) {
+        float4 xv[NV], t[NV];
+        load_row_f32<NV>(wte + (size_t)id * H, H, lane, xv);
+        if (att) {
+          load_row_f32<NV>(att + (size_t)b * att_stride, H, lane, t);
+#pragma unroll
+          for (int j = 0; j < NV; ++j) { xv[j].x += t[j].x; xv[j].y += t[j].y; xv[j].z += t[j].z; xv[j].w += t[j].w; }
+        }
+        add_head_terms<NV>(xa, b, s, S, H, lane, xv);
+        const float mean = mean_i[m], rstd = rstd_i[m];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          const int c = (j * 64 + lane) * 4;
+          if (c < H) {
+            xv[j].x = (xv[j].x - mean) * rstd; xv[j].y = (xv[j].y - mean) * rstd;
+            xv[j].z = (xv[j].z - mean) * rstd; xv[j].w = (xv[j].w - mean) * rstd;
+            dg[j].x += dy[j].x * xv[j].x; dg[j].y += dy[j].y * xv[j].y;
+            dg[j].z += dy[j].z * xv[j].z; dg[j].w += dy[j].w * xv[j].w;
+            db[j].x += dy[j].x; db[j].y += dy[j].y; db[j].z += dy[j].z; db[j].w += dy[j].w;
+            dy[j].x *= gm[j].x; dy[j].y *= gm[j].y; dy[j].z *= gm[j].z; dy[j].w *= gm[j].w;
+            c1 += dy[j].x + dy[j].y + dy[j].z + dy[j].w;
+            c2 += dy[j].x * xv[j].x + dy[j].y * xv[j].y + dy[j].z * xv[j].z + dy[j].w * xv[j].w;
+          }
+        }
+        c1 = wave_sum(c1) / (float)H;
+        c2 = wave_sum(c2) / (float)H;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+          dy[j].x = rstd * (dy[j].x - c1 - xv[j].x * c2); dy[j].y = rstd * (dy[j].y - c1 - xv[j].y * c2);
+          dy[j].z = rstd * (dy[j].z - c1 - xv[j].z * c2); dy[j].w = rstd * (dy[j].w - c1 - xv[j].w * c2);
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int c = (j * 64 + lane) * 4;
         if (c < H) {
-          xv[j].x = (xv[j].x - mean) * rstd; xv[j].y = (xv[j].y - mean) * rstd;
-          xv[j].z = (xv[j].z - mean) * rstd; xv[j].w = (xv[j].w - mean) * rstd;
-          dg[j].x += dy[j].x * xv[j].x; dg[j].y += dy[j].y * xv[j].y;
-          dg[j].z += dy[j].z * xv[j].z; dg[j].w += dy[j].w * xv[j].w;
-          db[j].x += dy[j].x; db[j].y += dy[j].y; db[j].z += dy[j].z; db[j].w += dy[j].w;
-          dy[j].x *= gm[j].x; dy[j].y *= gm[j].y; dy[j].z *= gm[j].z; dy[j].w *= gm[j].w;
-          c1 += dy[j].x + dy[j].y + dy[j].z + dy[j].w;
-          c2 += dy[j].x * xv[j].x + dy[j].y * xv[j].y + dy[j].z * xv[j].z + dy[j].w * xv[j].w;
+          atomic_add4(dwte + (size_t)id * H + c, dy[j]);
+          sa[j].x += dy[j].x; sa[j].y += dy[j].y; sa[j].z += dy[j].z; sa[j].w += dy[j].w;
         }
       }
-      c1 = wave_sum(c1) / (float)H;
-      c2 = wave_sum(c2) / (float)H;
+      if (xa.dU) {
+        if (ACCU) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        dy[j].x = rstd * (dy[j].x - c1 - xv[j].x * c2); dy[j].y = rstd * (dy[j].y - c1 - xv[j].y * c2);
-        dy[j].z = rstd * (dy[j].z - c1 - xv[j].z * c2); dy[j].w = rstd * (dy[j].w - c1 - xv[j].w * c2);
-      }
-    }
+          for (int h = 0; h < NH; ++h) {
+            if (h < xa.heads) {
+              const float w = xa.w(b, h, s, S);
 #pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int c = (j * 64 + lane) * 4;
-      if (c < H) {
-        atomic_add4(dwte + (size_t)id * H + c, dy[j]);
-        if (datt) atomic_add4(datt + (size_t)b * H + c, dy[j]);
-        if (xa.dU) {
+              for (int j = 0; j < NV; ++j) {
+                su[h][j].x += dy[j].x * w; su[h][j].y += dy[j].y * w; su[h][j].z += dy[j].z * w; su[h][j].w += dy[j].w * w;
+              }
+            }
+          }
+        } else {
           for (int h = 0; h < xa.heads; ++h) {
             const float w = xa.w(b, h, s, S);
             if (w != 0.f) {
-              const float4 dw = make_float4(dy[j].x * w, dy[j].y * w, dy[j].z * w, dy[j].w * w);
-              atomic_add4(xa.dU + ((size_t)b * xa.heads + h) * H + c, dw);
+#pragma unroll
+              for (int j = 0; j < NV; ++j) {
+                const int c = (j * 64 + lane) * 4;
+                if (c < H)
+                  atomic_add4(xa.dU + ((size_t)b * xa.heads + h) * H + c,
+                              make_float4(dy[j].x * w, dy[j].y * w, dy[j].z * w, dy[j].w * w));
+              }
             }
+          }
+        }
+      }
+    }
+    if (any) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < H) {
+          if (datt) atomic_add4(datt + (size_t)b * H + c, sa[j]);
+          if (ACCU && xa.dU) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+              if (h < xa.heads) atomic_add4(xa.dU + ((size_t)b * xa.heads + h) * H + c, su[h][j]);
           }
         }
       }
     }
   }
   if (part && gamma) write_partials<NV>(dg, db, H, part, gridDim.x, red);
+}
+
+// dwpe[s, :] += sum over sequences b of g[b, s, :] (masked rows skipped, embedding dropout replayed).
+// One thread owns 4 columns of one position and walks a slice of the batch: every load is a coalesced 16-B
+// vector, the gridDim.y batch slices meet through (gridDim.y-way) atomics.
+__global__ __launch_bounds__(256) void wpe_grad_kernel(const float* __restrict__ g, const int* __restrict__ row_mask,
+                                                       int B, int S, int H, float* __restrict__ dwpe, Drop drop_e,
+                                                       int bslice) {
+  const int h4 = H >> 2;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= S * h4) return;
+  const int s = idx / h4, c = (idx - s * h4) * 4;
+  const int b0 = blockIdx.y * bslice, b1 = min(B, b0 + bslice);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int b = b0; b < b1; ++b) {
+    const int m = b * S + s;
+    if (row_mask && row_mask[m] == 0) continue;
+    float4 v = *reinterpret_cast<const float4*>(g + (size_t)m * H + c);
+    if (drop_e.on()) {
+      const unsigned e = (unsigned)m * (unsigned)H + (unsigned)c;
+      v.x *= drop_e.mul(e); v.y *= drop_e.mul(e + 1); v.z *= drop_e.mul(e + 2); v.w *= drop_e.mul(e + 3);
+    }
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  atomic_add4(dwpe + (size_t)s * H + c, acc);
 }
 
 // ------------------------------------------------------------------------------------ column sums
@@ -631,7 +704,17 @@ extern "C" int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t 
   return check_launch("pgca_embed_fwd");
 }
 
-extern "C" int pgca_embed_bwd_blocks(int32_t B, int32_t S) { return pgca_layernorm_bwd_blocks(B * S); }
+static int embed_chunk(int S) {
+  int c = 16;
+  while (c > 1 && (S % c)) c >>= 1;
+  return c;
+}
+
+extern "C" int pgca_embed_bwd_blocks(int32_t B, int32_t S) {
+  const int nchunks = (B * S) / embed_chunk(S);
+  int b = (nchunks + 3) / 4;
+  return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
 
 extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t* row_mask, int32_t B, int32_t S,
                               int32_t H, const float* wte, const float* attended, const float* gamma,
@@ -649,8 +732,23 @@ extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t*
   const size_t lds = (size_t)2 * 4 * nv * 256 * sizeof(float);
   const XAttn xa{U, dU, xheads, drop_from_words(drop_x)};
   const Drop de = drop_from_words(drop_e);
-  DISPATCH_NV(nv, hipLaunchKernelGGL((embed_bwd_kernel<NV>), grid, block, lds, s, g, (const long long*)ids, row_mask, B,
-                                     S, H, wte, attended, gamma, mean, rstd, dwte, dwpe, dattended, part, att_stride, xa,
-                                     de));
+  const int chunk = embed_chunk(S);
+  if (nv <= 4 && xheads <= 8) {
+    DISPATCH_NV(nv, hipLaunchKernelGGL((embed_bwd_kernel<(NV <= 4 ? NV : 4), true>), grid, block, lds, s, g,
+                                       (const long long*)ids, row_mask, B, S, H, wte, attended, gamma, mean, rstd, dwte,
+                                       dattended, part, att_stride, xa, de, chunk));
+  } else {
+    DISPATCH_NV(nv, hipLaunchKernelGGL((embed_bwd_kernel<NV, false>), grid, block, lds, s, g, (const long long*)ids,
+                                       row_mask, B, S, H, wte, attended, gamma, mean, rstd, dwte, dattended, part,
+                                       att_stride, xa, de, chunk));
+  }
+  {
+    const int nthr = S * (H >> 2);
+    int ys = B >= 64 ? 8 : (B >= 8 ? 2 : 1);
+    const int bslice = (B + ys - 1) / ys;
+    ys = (B + bslice - 1) / bslice;
+    hipLaunchKernelGGL(wpe_grad_kernel, dim3((nthr + 255) / 256, ys), dim3(256), 0, s, g, row_mask, B, S, H, dwpe, de,
+                       bslice);
+  }
   return check_launch("pgca_embed_bwd");
 }

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--ring", type=int, default=-1)
+    ap.add_argument("--timing", action="store_true", help="needs gemm_wide.o built with -DPGCA_GEMM_TIMING")
     args = ap.parse_args()
     if args.tile:
         os.environ["PGCA_GEMM_TILE"] = str(args.tile)
@@ -71,6 +72,10 @@ def main():
                       stat_max=torch.empty(M, nparts, device=dev), stat_sum=torch.empty(M, nparts, device=dev),
                       stat_ld=nparts, target_val=torch.empty(M, device=dev))
 
+        if args.timing and epi in ("none", "bias"):
+            tbuf = torch.zeros(((M + 255) // 256) * ((N + 255) // 256) * 4 * 8, device=dev)
+            kw["stat_max"] = tbuf
+
         def run():
             hip.gemm(A, B, M, N, K, layout, **kw)
 
@@ -84,6 +89,12 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / args.iters
+        if args.timing and "stat_max" in kw and epi != "rowstats":
+            tb = kw["stat_max"].view(-1, 8).cpu()
+            m = tb.mean(0)
+            steps = float(m[5])
+            print(f"   per-step ticks: mma {m[0] / steps:.1f} vmwait {m[6] / steps:.1f} barrier {m[1] / steps:.1f} "
+                  f"dma-issue {m[2] / steps:.1f} lgkm {m[3] / steps:.1f} total {m[4] / steps:.1f}")
         print(f"{name:10s} layout={layout} M={M:6d} N={N:6d} K={K:6d} {epi:8s} {us:9.1f} us  "
               f"{2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
 
