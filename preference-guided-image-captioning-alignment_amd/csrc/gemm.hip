@@ -197,10 +197,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a,
   const int nk = min(nk_per_split, a.K / BK - kt0);
   abase += (size_t)kt0 * astep;
   bbase += (size_t)kt0 * bstep;
+#ifdef PGCA_GEMM_TIMING
+  unsigned long long ts0, ts1, ts2, ts3;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory");
+#endif
   da.issue(abase, smem2, wave);
   db.issue(bbase, smem2 + TILE2_BYTES, wave);
   dma_wait();
   __syncthreads();
+#ifdef PGCA_GEMM_TIMING
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory");
+#endif
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -223,440 +230,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a,
     __syncthreads();  // ... and every wave is done reading tile kt
   }
 
+#ifdef PGCA_GEMM_TIMING
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts2)::"memory");
+#endif
   run_epilogue(a, acc[0], smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
   run_epilogue(a, acc[1], smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Ring variant of the 256^2 kernel: BK = 32, FOUR LDS stages of (A 16 KiB | B 16 KiB), three K tiles
-// of LDS-DMA in flight.  Each wave retires only the OLDEST tile with a counted `s_waitcnt vmcnt(N)`
-// (N = 4 DMA instructions x tiles still allowed in flight) before the one barrier per tile, so HBM/L2
-// latency is covered by up to three tiles of MFMA work instead of one.
-// ------------------------------------------------------------------------------------------------
-constexpr int RBK = 32, RSTAGES = 4;
-constexpr int RTILE_BYTES = 256 * RBK * 2;  // 16 KiB per operand per stage
-
-__device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }  // {0,2,3,1}
-
-template <int KS>
-struct DmaR {
-  unsigned goff[2];
-  __device__ __forceinline__ void init(int lane, int wave, int ld, int origin, int extent) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int j = wave * 2 + i;  // 1-KiB piece of the 16-KiB tile image
-      if (KS == 0) {               // [256 rows][32 k]: piece = 16 rows x 64 B; chunk c of row r at c ^ swz4((r>>2)&3)
-        const int r = 16 * j + (lane >> 2);
-        const int c = (lane & 3) ^ swz4((lane >> 4) & 3);
-        const int rg = min(origin + r, extent - 1) - origin;
-        goff[i] = (unsigned)(rg * ld + c * 8) * 2u;
-      } else {                     // [32 k][256 cols]: piece = 2 k-rows x 512 B (same image as the BK = 64 kernel)
-        const int k = 2 * j + (lane >> 5);
-        const int c16 = lane & 31;
-        const int h = (k & 3) | (((k >> 3) & 1) << 2);
-        const int col = (((c16 >> 1) ^ h) << 4) + ((c16 & 1) << 3);
-        const int cg = min(origin + col, extent - 8) - origin;
-        goff[i] = (unsigned)(k * ld + cg) * 2u;
-      }
-    }
+#ifdef PGCA_GEMM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts3)::"memory");
+  if (a.stat_max && a.epilogue != PGCA_EPI_ROWSTATS && lane == 0) {
+    float* o = a.stat_max + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)(ts3 - ts2); o[3] = (float)nk;
   }
-  __device__ __forceinline__ void issue(const bf16_t* base, unsigned char* tile, int wave) const {
-    const unsigned long long b = (unsigned long long)base;
-    u32x4 rs;
-    rs[0] = (unsigned)b;
-    rs[1] = (unsigned)(b >> 32) & 0xffffu;
-    rs[2] = 0x7ffffff0u;
-    rs[3] = 0x00020000u;
-    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(tile) + (unsigned)wave * 2048u;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      asm volatile("s_nop 4\n\ts_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                   :
-                   : "s"(lds0 + i * 1024u), "v"(goff[i]), "s"(rs)
-                   : "memory");
-    }
-  }
-};
-
-template <int KS>
-__device__ __forceinline__ bf16x8 read_frag_r(const unsigned char* lds, int wbase, int sub, int lane) {
-  if (KS == 0) {
-    const int row = wbase + sub * 16 + (lane & 15);
-    const int pos = (lane >> 4) ^ swz4((lane >> 2) & 3);
-    return *reinterpret_cast<const bf16x8*>(lds + row * 64 + pos * 16);
-  } else {
-    return read_frag<1, 512>(lds, wbase, sub, 0, lane);
-  }
-}
-
-template <int LA>
-__device__ __forceinline__ void mma_half_r(const unsigned char* la, int row0, int lane, const bf16x8 (&fb)[4],
-                                           f32x4 (&acc)[4][4]) {
-  bf16x8 fa[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa[i] = read_frag_r<LA>(la, row0, i, lane);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-}
-
-template <int LA, int LB>
-__global__ __launch_bounds__(512, 2) void gemm256r_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [4 stages][A | B][16 KiB]
-
-  const int nwg = ntm * ntn;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * ntn;
-  const int group = bid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(GROUP_M, ntm - first_m);
-  const int in_group = bid - group * per_group;
-  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
-  const int m0 = tm * BM2, n0 = tn * BN2;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
-
-  DmaR<LA> da;
-  DmaR<LB> db;
-  da.init(lane, wave, a.lda, m0, LA == 0 ? a.M : ((a.M + 7) & ~7));
-  db.init(lane, wave, a.ldb, n0, LB == 0 ? a.N : ((a.N + 7) & ~7));
-  const bf16_t* abase = LA == 0 ? A + (size_t)m0 * a.lda : A + m0;
-  const bf16_t* bbase = LB == 0 ? B + (size_t)n0 * a.ldb : B + n0;
-  const size_t astep = LA == 0 ? (size_t)RBK : (size_t)RBK * a.lda;
-  const size_t bstep = LB == 0 ? (size_t)RBK : (size_t)RBK * a.ldb;
-
-  f32x4 acc[2][4][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // split-K in units of 64-deep tiles (two ring tiles each) like the BK = 64 kernel
-  const int kt0 = blockIdx.y * nk_per_split * 2;
-  const int nk = min(nk_per_split * 2, a.K / RBK - kt0);
-  abase += (size_t)kt0 * astep;
-  bbase += (size_t)kt0 * bstep;
-
-#pragma unroll
-  for (int p = 0; p < RSTAGES - 1; ++p) {
-    if (p < nk) {
-      da.issue(abase + (size_t)p * astep, smem2 + p * 2 * RTILE_BYTES, wave);
-      db.issue(bbase + (size_t)p * bstep, smem2 + p * 2 * RTILE_BYTES + RTILE_BYTES, wave);
-    }
-  }
-
-  for (int kt = 0; kt < nk; ++kt) {
-    // tiles kt+1, kt+2 (if they exist) may stay in flight: 4 DMA instructions per tile per wave
-    const int rem = nk - 1 - kt;
-    if (rem >= 2) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else if (rem == 1) {
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();  // every wave's pieces of tile kt have landed; everyone is done reading tile kt-1
-    if (kt + RSTAGES - 1 < nk) {
-      unsigned char* nxt = smem2 + ((kt + RSTAGES - 1) & (RSTAGES - 1)) * 2 * RTILE_BYTES;
-      da.issue(abase + (size_t)(kt + RSTAGES - 1) * astep, nxt, wave);
-      db.issue(bbase + (size_t)(kt + RSTAGES - 1) * bstep, nxt + RTILE_BYTES, wave);
-    }
-    const unsigned char* la = smem2 + (kt & (RSTAGES - 1)) * 2 * RTILE_BYTES;
-    const unsigned char* lb = la + RTILE_BYTES;
-    bf16x8 fb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = read_frag_r<LB>(lb, wn * 64, j, lane);
-    mma_half_r<LA>(la, wm * 128, lane, fb, acc[0]);
-    mma_half_r<LA>(la, wm * 128 + 64, lane, fb, acc[1]);
-  }
-  __syncthreads();  // the epilogue stages through the same LDS
-
-  run_epilogue(a, acc[0], smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
-  run_epilogue(a, acc[1], smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Phased variant of the 256^2 kernel.  A 512-thread workgroup puts two waves on every SIMD (wave w and
-// w + 4).  Here the two halves of the workgroup (waves 0-3 = top 128 rows, waves 4-7 = bottom 128 rows)
-// run the SAME schedule one phase apart, every phase closed by one s_barrier:
-//     half 0:  R0  M0  R1  M1 | R0  M0 ...        R = fragment reads of one 32-deep k-step (LDS -> VGPR)
-//     half 1:      R0  M0  R1 | M1  R0 ...        M = its 32 MFMAs
-// so on each SIMD one wave always owns the matrix pipe while its partner fetches operands: the pipe
-// never waits for LDS latency and the two waves never fight for it.  The LDS-DMA of tile t+1 is issued
-// in the first phase of tile t and retired (vmcnt(0)) in its last phase: four phases of flight.
-// ------------------------------------------------------------------------------------------------
-#define PGCA_PHASE_BARRIER()              \
-  do {                                    \
-    __builtin_amdgcn_sched_barrier(0);    \
-    __builtin_amdgcn_s_barrier();         \
-    __builtin_amdgcn_sched_barrier(0);    \
-  } while (0)
-
-template <int LA, int LB>
-__device__ __forceinline__ void load_frags_p(const unsigned char* la, const unsigned char* lb, int arow0, int bcol0,
-                                             int kk, int lane, bf16x8 (&fa0)[4], bf16x8 (&fa1)[4], bf16x8 (&fb)[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) fb[j] = read_frag<LB, 512>(lb, bcol0, j, kk, lane);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa0[i] = read_frag<LA, 512>(la, arow0, i, kk, lane);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa1[i] = read_frag<LA, 512>(la, arow0 + 64, i, kk, lane);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
-
-__device__ __forceinline__ void mma32_p(const bf16x8 (&fa0)[4], const bf16x8 (&fa1)[4], const bf16x8 (&fb)[4],
-                                        f32x4 (&acc0)[4][4], f32x4 (&acc1)[4][4]) {
-  __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa0[i], fb[j], acc0[i][j], 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa1[i], fb[j], acc1[i][j], 0, 0, 0);
-  __builtin_amdgcn_s_setprio(0);
-}
-
-template <int LA, int LB>
-__global__ __launch_bounds__(512, 2) void gemm256p_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [2 stages][A | B][32 KiB]
-
-  const int nwg = ntm * ntn;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * ntn;
-  const int group = bid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(GROUP_M, ntm - first_m);
-  const int in_group = bid - group * per_group;
-  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
-  const int m0 = tm * BM2, n0 = tn * BN2;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;  // wm doubles as the phase half
-
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
-
-  Dma<LA> da;
-  Dma<LB> db;
-  da.init(lane, wave, a.lda, m0, LA == 0 ? a.M : ((a.M + 7) & ~7));
-  db.init(lane, wave, a.ldb, n0, LB == 0 ? a.N : ((a.N + 7) & ~7));
-  const bf16_t* abase = LA == 0 ? A + (size_t)m0 * a.lda : A + m0;
-  const bf16_t* bbase = LB == 0 ? B + (size_t)n0 * a.ldb : B + n0;
-  const size_t astep = LA == 0 ? (size_t)BK : (size_t)BK * a.lda;
-  const size_t bstep = LB == 0 ? (size_t)BK : (size_t)BK * a.ldb;
-
-  f32x4 acc0[4][4], acc1[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int kt0 = blockIdx.y * nk_per_split;
-  const int nk = min(nk_per_split, a.K / BK - kt0);
-  abase += (size_t)kt0 * astep;
-  bbase += (size_t)kt0 * bstep;
-  da.issue(abase, smem2, wave);
-  db.issue(bbase, smem2 + TILE2_BYTES, wave);
-  dma_wait();
-  PGCA_PHASE_BARRIER();
-
-  const int arow0 = wm * 128, bcol0 = wn * 64;
-  bf16x8 fa0[4], fa1[4], fb[4];
-  if (wm == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned char* la = smem2 + (kt & 1) * 2 * TILE2_BYTES;
-      const unsigned char* lb = la + TILE2_BYTES;
-      if (kt + 1 < nk) {
-        unsigned char* nxt = smem2 + ((kt + 1) & 1) * 2 * TILE2_BYTES;
-        da.issue(abase + (size_t)(kt + 1) * astep, nxt, wave);
-        db.issue(bbase + (size_t)(kt + 1) * bstep, nxt + TILE2_BYTES, wave);
-      }
-      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 0, lane, fa0, fa1, fb);  // R0
-      PGCA_PHASE_BARRIER();
-      mma32_p(fa0, fa1, fb, acc0, acc1);                                   // M0
-      PGCA_PHASE_BARRIER();
-      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 1, lane, fa0, fa1, fb);  // R1
-      PGCA_PHASE_BARRIER();
-      mma32_p(fa0, fa1, fb, acc0, acc1);                                   // M1
-      dma_wait();
-      PGCA_PHASE_BARRIER();
-    }
-    PGCA_PHASE_BARRIER();  // the other half's trailing M1
-  } else {
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned char* la = smem2 + (kt & 1) * 2 * TILE2_BYTES;
-      const unsigned char* lb = la + TILE2_BYTES;
-      if (kt + 1 < nk) {
-        unsigned char* nxt = smem2 + ((kt + 1) & 1) * 2 * TILE2_BYTES;
-        da.issue(abase + (size_t)(kt + 1) * astep, nxt, wave);
-        db.issue(bbase + (size_t)(kt + 1) * bstep, nxt + TILE2_BYTES, wave);
-      }
-      if (kt > 0) mma32_p(fa0, fa1, fb, acc0, acc1);                       // M1 of the previous tile
-      PGCA_PHASE_BARRIER();
-      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 0, lane, fa0, fa1, fb);  // R0
-      PGCA_PHASE_BARRIER();
-      mma32_p(fa0, fa1, fb, acc0, acc1);                                   // M0
-      PGCA_PHASE_BARRIER();
-      load_frags_p<LA, LB>(la, lb, arow0, bcol0, 1, lane, fa0, fa1, fb);  // R1
-      dma_wait();
-      PGCA_PHASE_BARRIER();
-    }
-    mma32_p(fa0, fa1, fb, acc0, acc1);                                     // M1 of the last tile
-    PGCA_PHASE_BARRIER();
-  }
-
-  run_epilogue(a, acc0, smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
-  run_epilogue(a, acc1, smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Phased ring: the two ideas together.  32-deep K tiles in a 4-stage LDS ring (three tiles of LDS-DMA
-// in flight, counted vmcnt) AND the two workgroup halves one phase apart, so that per 512-cycle phase
-// each SIMD has one wave issuing 32 MFMAs while its partner reads the next fragments and issues its
-// four 1-KiB DMA pieces - vector-memory issue (64 B/clk/CU through the texture path) never sits in
-// front of MFMAs in a wave's instruction stream.
-//     half 0:  R(0) M(0) R(1) M(1) ...
-//     half 1:   -   R(0) M(0) R(1) ...
-// ------------------------------------------------------------------------------------------------
-template <int LA, int LB>
-__device__ __forceinline__ void load_frags_q(const unsigned char* la, const unsigned char* lb, int arow0, int bcol0,
-                                             int lane, bf16x8 (&fa0)[4], bf16x8 (&fa1)[4], bf16x8 (&fb)[4]) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) fb[j] = read_frag_r<LB>(lb, bcol0, j, lane);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa0[i] = read_frag_r<LA>(la, arow0, i, lane);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) fa1[i] = read_frag_r<LA>(la, arow0 + 64, i, lane);
-}
-
-__device__ __forceinline__ void wait_tiles_in_flight(int n) {  // n = later tiles that may stay in flight (0..2)
-  if (n >= 2) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  } else if (n == 1) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-}
-
-template <int LA, int LB>
-__global__ __launch_bounds__(512, 2) void gemm256q_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [4 stages][A | B][16 KiB]
-
-  const int nwg = ntm * ntn;
-  int bid = blockIdx.x;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * ntn;
-  const int group = bid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(GROUP_M, ntm - first_m);
-  const int in_group = bid - group * per_group;
-  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
-  const int m0 = tm * BM2, n0 = tn * BN2;
-
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(a.A);
-  const bf16_t* B = reinterpret_cast<const bf16_t*>(a.B);
-
-  DmaR<LA> da;
-  DmaR<LB> db;
-  da.init(lane, wave, a.lda, m0, LA == 0 ? a.M : ((a.M + 7) & ~7));
-  db.init(lane, wave, a.ldb, n0, LB == 0 ? a.N : ((a.N + 7) & ~7));
-  const bf16_t* abase = LA == 0 ? A + (size_t)m0 * a.lda : A + m0;
-  const bf16_t* bbase = LB == 0 ? B + (size_t)n0 * a.ldb : B + n0;
-  const size_t astep = LA == 0 ? (size_t)RBK : (size_t)RBK * a.lda;
-  const size_t bstep = LB == 0 ? (size_t)RBK : (size_t)RBK * a.ldb;
-
-  f32x4 acc0[4][4], acc1[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc0[i][j] = acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int kt0 = blockIdx.y * nk_per_split * 2;
-  const int nk = min(nk_per_split * 2, a.K / RBK - kt0);
-  abase += (size_t)kt0 * astep;
-  bbase += (size_t)kt0 * bstep;
-
-#pragma unroll
-  for (int p = 0; p < RSTAGES - 1; ++p) {
-    if (p < nk) {
-      da.issue(abase + (size_t)p * astep, smem2 + p * 2 * RTILE_BYTES, wave);
-      db.issue(bbase + (size_t)p * bstep, smem2 + p * 2 * RTILE_BYTES + RTILE_BYTES, wave);
-    }
-  }
-  wait_tiles_in_flight(min(2, nk - 1));
-  PGCA_PHASE_BARRIER();  // tile 0 is in LDS
-
-  const int arow0 = wm * 128, bcol0 = wn * 64;
-  bf16x8 fa0[4], fa1[4], fb[4];
-  if (wm == 0) {
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned char* la = smem2 + (kt & 3) * 2 * RTILE_BYTES;
-      load_frags_q<LA, LB>(la, la + RTILE_BYTES, arow0, bcol0, lane, fa0, fa1, fb);        // R(kt)
-      if (kt + 3 < nk) {
-        unsigned char* nxt = smem2 + ((kt + 3) & 3) * 2 * RTILE_BYTES;
-        da.issue(abase + (size_t)(kt + 3) * astep, nxt, wave);
-        db.issue(bbase + (size_t)(kt + 3) * bstep, nxt + RTILE_BYTES, wave);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      PGCA_PHASE_BARRIER();
-      mma32_p(fa0, fa1, fb, acc0, acc1);                                                    // M(kt)
-      wait_tiles_in_flight(min(2, nk - 2 - kt));   // own pieces of tile kt+1 have landed
-      PGCA_PHASE_BARRIER();
-    }
-    PGCA_PHASE_BARRIER();  // the other half's trailing M
-  } else {
-    PGCA_PHASE_BARRIER();  // half 0 reads tile 0 first
-    for (int kt = 0; kt < nk; ++kt) {
-      const unsigned char* la = smem2 + (kt & 3) * 2 * RTILE_BYTES;
-      load_frags_q<LA, LB>(la, la + RTILE_BYTES, arow0, bcol0, lane, fa0, fa1, fb);        // R(kt)
-      if (kt + 3 < nk) {
-        unsigned char* nxt = smem2 + ((kt + 3) & 3) * 2 * RTILE_BYTES;
-        da.issue(abase + (size_t)(kt + 3) * astep, nxt, wave);
-        db.issue(bbase + (size_t)(kt + 3) * bstep, nxt + RTILE_BYTES, wave);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      wait_tiles_in_flight(min(2, nk - 2 - kt));   // own pieces of tile kt+1 have landed
-      PGCA_PHASE_BARRIER();
-      mma32_p(fa0, fa1, fb, acc0, acc1);                                                    // M(kt)
-      PGCA_PHASE_BARRIER();
-    }
-  }
-
-  run_epilogue(a, acc0, smem2, m0 + wm * 128, n0, tn, wn, lane, wave);
-  run_epilogue(a, acc1, smem2, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
+#endif
 }
 
 constexpr size_t GEMM256_LDS = 4 * TILE2_BYTES;  // 128 KiB
@@ -670,27 +255,7 @@ int ensure_gemm256_attr() {
                                         (int)GEMM256_LDS);
     hipError_t e3 = hipFuncSetAttribute((const void*)gemm256_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GEMM256_LDS);
-    hipError_t e4 = hipFuncSetAttribute((const void*)gemm256r_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)GEMM256_LDS);
-    hipError_t e5 = hipFuncSetAttribute((const void*)gemm256r_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)GEMM256_LDS);
-    hipError_t e6 = hipFuncSetAttribute((const void*)gemm256r_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)GEMM256_LDS);
-    hipError_t e7 = hipFuncSetAttribute((const void*)gemm256p_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)GEMM256_LDS);
-    hipError_t e8 = hipFuncSetAttribute((const void*)gemm256p_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)GEMM256_LDS);
-    hipError_t e9 = hipFuncSetAttribute((const void*)gemm256p_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)GEMM256_LDS);
-    hipError_t e10 = hipFuncSetAttribute((const void*)gemm256q_kernel<0, 0>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM256_LDS);
-    hipError_t e11 = hipFuncSetAttribute((const void*)gemm256q_kernel<0, 1>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM256_LDS);
-    hipError_t e12 = hipFuncSetAttribute((const void*)gemm256q_kernel<1, 1>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM256_LDS);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess ||
-        e6 != hipSuccess || e7 != hipSuccess || e8 != hipSuccess || e9 != hipSuccess || e10 != hipSuccess ||
-        e11 != hipSuccess || e12 != hipSuccess) {
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm256: cannot raise dynamic LDS limit");
       return PGCA_ERR_LAUNCH;
@@ -724,14 +289,16 @@ int plan_tile(const pgca_gemm_args& a, int* splits_out) {
 
 }  // namespace
 
-// Main-loop schedule of the 256^2 kernel: 0 = 2-stage BK=64, 1 = 4-stage BK=32 ring, 2 = phased halves,
-// 3 = phased ring.  Measured on MI355X (tools/gemm_bench.py): in isolation the phased ring wins on long-K NT/NN
-// (+5..9 % at K = 4096), the plain 2-stage loop on K = 1024 and on the K-strided TN weight gradients.
+// Schedule of the 256^2 tile: 0 = gemm256_kernel (8 waves, 2-stage BK=64, the default), 4 = gemm256w_kernel
+// (gemm_wide.hip: 4 waves x 128x128, asm-pipelined 4-stage BK=32 ring; slower today, selectable with
+// PGCA_GEMM_RING=4).  Earlier 8-wave schedules (BK=32 ring, phased halves, phased ring) measured within +-10 % of
+// the default in isolation and equal end to end and were removed; DESIGN.md section 5 has the numbers.
 static int plan_variant(const pgca_gemm_args& a) {
   const char* env = getenv("PGCA_GEMM_RING");
-  if (env) return atoi(env);
   (void)a;
-  return 0;  // end-to-end the plain loop is as fast as the mixed policy (820 vs 827 pairs/s): one kernel, one schedule
+  if (env && atoi(env) == 4) return 4;
+  if (env && atoi(env) == 5) return 5;
+  return 0;
 }
 
 extern "C" int pgca_gemm_plan(const pgca_gemm_args* args) {
@@ -799,36 +366,10 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       const int nkps = (nk_total + splits - 1) / splits;
       dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
       const int variant = plan_variant(a);
+      if (variant == 5) return launch_gemm_duo(b, nkps, (int)grid2.y, stream);
       if (variant == 4) {
         const int rc = launch_gemm256w(b, ntm2, ntn2, nkps, (int)grid2.y, stream);
         if (rc != 1) return rc;  // 1: epilogue not implemented by the wide-wave kernel, use the 8-wave one
-      }
-      if (variant == 3) {
-        switch (a.layout) {
-          case PGCA_NT: hipLaunchKernelGGL((gemm256q_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          case PGCA_NN: hipLaunchKernelGGL((gemm256q_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          case PGCA_TN: hipLaunchKernelGGL((gemm256q_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
-        }
-        return check_launch("pgca_gemm_bf16(256 phased ring)");
-      }
-      if (variant == 2) {
-        switch (a.layout) {
-          case PGCA_NT: hipLaunchKernelGGL((gemm256p_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          case PGCA_NN: hipLaunchKernelGGL((gemm256p_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          case PGCA_TN: hipLaunchKernelGGL((gemm256p_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
-        }
-        return check_launch("pgca_gemm_bf16(256 phased)");
-      }
-      if (variant == 1) {
-        switch (a.layout) {
-          case PGCA_NT: hipLaunchKernelGGL((gemm256r_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          case PGCA_NN: hipLaunchKernelGGL((gemm256r_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          case PGCA_TN: hipLaunchKernelGGL((gemm256r_kernel<1, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
-          default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
-        }
-        return check_launch("pgca_gemm_bf16(256 ring)");
       }
       switch (a.layout) {
         case PGCA_NT: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;

@@ -1,6 +1,6 @@
 // Device-side building blocks shared by the GEMM translation units (gemm.hip, gemm_wide.hip): operand staging
 // geometry, MFMA fragment readers, the fused epilogues and the LDS-DMA issue helpers.  Everything here has
-// internal linkage; the only cross-TU symbol is pgca::launch_gemm256w (defined in gemm_wide.hip).
+// internal linkage; the cross-TU symbols are pgca::launch_gemm256w (gemm_wide.hip) and pgca::launch_gemm_duo (gemm_duo.hip).
 #pragma once
 #include <stdlib.h>
 
@@ -10,6 +10,8 @@ namespace pgca {
 // Wide-wave 256 x 256 kernel (gemm_wide.hip).  Returns 0 when launched, 1 when the epilogue/layout is not
 // one it implements (caller falls back to the 8-wave kernel), < 0 on error.
 int launch_gemm256w(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int nsplit, void* stream);
+// 256 x 128 tile, 4 waves, two workgroups per CU (gemm_duo.hip).  nk_per_split in 64-deep tiles.
+int launch_gemm_duo(const pgca_gemm_args& a, int nk_per_split, int nsplit, void* stream);
 }  // namespace pgca
 
 using namespace pgca;
@@ -248,6 +250,154 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
   }
 }
 
+// ---- fast epilogue ---------------------------------------------------------------------------------
+// Interior, 16-B-aligned 64 x 64 blocks (all of the hot path).  What the general path below costs is not
+// arithmetic but LATENCY: it loads the bias / residual stream / saved activation of 8 rows, waits, finishes them,
+// stores, and only then loads the next 8 rows - 16 dependent HBM round trips per 64 x 64 block pair, with the
+// matrix pipe idle (s_memtime: 35-66k clocks of epilogue against 52k of main loop at K = 1024).  Here every
+// global operand of the whole block is requested up front (one round trip), no lane predicates, no block barriers
+// (the staging buffer is private to the wave and a wave's LDS operations execute in order).
+enum { PF_NONE = 0, PF_RES = 1, PF_ACC = 2 };
+
+template <int EPI, int PF>
+__device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem,
+                                                    int mb, int cb, int lane, int wave) {
+  constexpr int LDC = 68;
+  constexpr bool AUXIN = EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH;
+  float* cbuf = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+  const int r8 = lane >> 3, cg = (lane & 7) * 8;
+  const int col = cb + cg;
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  if (a.bias) {
+    b0 = *reinterpret_cast<const float4*>(a.bias + col);
+    b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
+  }
+  float4 pre[PF != PF_NONE ? 8 : 1][2];
+  bf16x8 ax[AUXIN ? 8 : 1];
+  float lse[EPI == PGCA_EPI_DLOGITS ? 8 : 1], rsc[EPI == PGCA_EPI_DLOGITS ? 8 : 1];
+  long long tgt[EPI == PGCA_EPI_DLOGITS ? 8 : 1];
+#pragma unroll
+  for (int i8 = 0; i8 < 8; ++i8) {
+    const int row = mb + i8 * 8 + r8;
+    if (PF == PF_RES) {
+      const float* p = a.residual + (size_t)row * a.ld_res + col;
+      pre[PF != PF_NONE ? i8 : 0][0] = *reinterpret_cast<const float4*>(p);
+      pre[PF != PF_NONE ? i8 : 0][1] = *reinterpret_cast<const float4*>(p + 4);
+    } else if (PF == PF_ACC) {
+      const float* p = a.out_f32 + (size_t)row * a.ld_out_f32 + col;
+      pre[PF != PF_NONE ? i8 : 0][0] = *reinterpret_cast<const float4*>(p);
+      pre[PF != PF_NONE ? i8 : 0][1] = *reinterpret_cast<const float4*>(p + 4);
+    }
+    if (AUXIN)
+      ax[AUXIN ? i8 : 0] =
+          *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.aux_in) + (size_t)row * a.ld_aux + col);
+    if (EPI == PGCA_EPI_DLOGITS) {
+      lse[EPI == PGCA_EPI_DLOGITS ? i8 : 0] = a.row_lse[row];
+      rsc[EPI == PGCA_EPI_DLOGITS ? i8 : 0] = a.row_scale[row];
+      tgt[EPI == PGCA_EPI_DLOGITS ? i8 : 0] = a.targets[row];
+    }
+  }
+  const Drop d{a.drop_seed, a.drop_threshold, a.drop_scale};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cbuf[(mh * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = acc[half * 2 + mh][ni][r];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int i8 = half * 4 + it;
+      const int lr = it * 8 + r8;
+      const int row = mb + half * 32 + lr;
+      const float4 c0 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + cg);
+      const float4 c1 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + cg + 4);
+      float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= a.alpha;
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      if (EPI == PGCA_EPI_GELU_NEW || EPI == PGCA_EPI_QUICK_GELU) {
+        if (a.aux_out) {
+          bf16x8 tq;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tq[j] = f2bf(v[j]);
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col) = tq;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = EPI == PGCA_EPI_GELU_NEW ? gelu_new(v[j]) : quick_gelu(v[j]);
+      } else if (EPI == PGCA_EPI_RELU) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+      } else if (EPI == PGCA_EPI_TANH) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fast_tanh(v[j]);
+        if (a.aux_out) {
+          bf16x8 tq;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tq[j] = f2bf(v[j]);
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col) = tq;
+        }
+      } else if (AUXIN) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = bf2f(ax[AUXIN ? i8 : 0][j]);
+          if (EPI == PGCA_EPI_DGELU_NEW) v[j] *= dgelu_new(x);
+          else if (EPI == PGCA_EPI_DRELU) v[j] = x > 0.f ? v[j] : 0.f;
+          else v[j] *= 1.f - x * x;
+        }
+      } else if (EPI == PGCA_EPI_DLOGITS) {
+        constexpr int q = EPI == PGCA_EPI_DLOGITS ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = (col + j) < a.N ? rsc[q * i8] * (__expf(v[j] - lse[q * i8]) - ((col + j) == tgt[q * i8] ? 1.f : 0.f)) : 0.f;
+      }
+      if (a.drop_threshold) {
+        const unsigned base = (unsigned)row * (unsigned)a.N + (unsigned)col;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= d.mul(base + j);
+      }
+      if (PF == PF_RES) {
+        const float4 p0 = pre[PF != PF_NONE ? i8 : 0][0], p1 = pre[PF != PF_NONE ? i8 : 0][1];
+        v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+      }
+      if (a.out_f32) {
+        float4 o0 = make_float4(v[0], v[1], v[2], v[3]), o1 = make_float4(v[4], v[5], v[6], v[7]);
+        if (PF == PF_ACC) {
+          const float4 p0 = pre[PF != PF_NONE ? i8 : 0][0], p1 = pre[PF != PF_NONE ? i8 : 0][1];
+          o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w; o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+        }
+        float* p = a.out_f32 + (size_t)row * a.ld_out_f32 + col;
+        *reinterpret_cast<float4*>(p) = o0;
+        *reinterpret_cast<float4*>(p + 4) = o1;
+      }
+      if (a.out_bf16) {
+        bf16x8 tq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tq[j] = f2bf(v[j]);
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.out_bf16) + (size_t)row * a.ld_out_bf16 + col) = tq;
+      }
+    }
+  }
+}
+
+// Uniform (per wave) test for the fast path: block inside the matrix, every pointer it touches 16-B aligned.
+template <int EPI>
+__device__ __forceinline__ bool epilogue_fast_ok(const pgca_gemm_args& a, int mb, int cb) {
+  const int ncols = EPI == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
+  if (a.accumulate == 2 || mb + 64 > a.M || cb + 64 > ncols) return false;
+  if (a.residual && a.out_f32 && a.accumulate) return false;
+  bool ok = true;
+  if (a.bias) ok = ok && al16(a.bias);
+  if (a.residual) ok = ok && al16(a.residual) && !(a.ld_res & 3);
+  if (a.out_f32) ok = ok && al16(a.out_f32) && !(a.ld_out_f32 & 3);
+  if (a.out_bf16) ok = ok && al16(a.out_bf16) && !(a.ld_out_bf16 & 7);
+  if (a.aux_out) ok = ok && al16(a.aux_out) && !(a.ld_aux & 7);
+  if (a.aux_in) ok = ok && al16(a.aux_in) && !(a.ld_aux & 7);
+  return ok;
+}
+
 // The wave's 64x64 accumulator tile goes through LDS in two 32-row halves (row stride 68 floats: conflict-free
 // b32 writes in the MFMA layout, b128 reads of 8 consecutive columns), so every global access of the epilogue
 // (bias, saved activations, residual stream, outputs) is a 16-byte vector op on 128..256 contiguous bytes per row.
@@ -255,6 +405,18 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int m0,
                                                int n0, int wm, int wn, int lane, int wave) {
   constexpr int LDC = 68;
+  if (epilogue_fast_ok<EPI>(a, m0 + wm * 64, n0 + wn * 64)) {  // wave-uniform
+    const int mb = m0 + wm * 64, cb = n0 + wn * 64;
+    if (a.residual) epilogue_store_fast<EPI, PF_RES>(a, acc, smem, mb, cb, lane, wave);
+    else if (a.out_f32 && a.accumulate) epilogue_store_fast<EPI, PF_ACC>(a, acc, smem, mb, cb, lane, wave);
+    else epilogue_store_fast<EPI, PF_NONE>(a, acc, smem, mb, cb, lane, wave);
+    // keep the block barriers of the general path below: other waves of the block may be on it
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   float* cbuf = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
   const int ncols = EPI == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
 #pragma unroll

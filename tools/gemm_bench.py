@@ -72,8 +72,8 @@ def main():
                       stat_max=torch.empty(M, nparts, device=dev), stat_sum=torch.empty(M, nparts, device=dev),
                       stat_ld=nparts, target_val=torch.empty(M, device=dev))
 
-        if args.timing and epi in ("none", "bias"):
-            tbuf = torch.zeros(((M + 255) // 256) * ((N + 255) // 256) * 4 * 8, device=dev)
+        if args.timing and epi != "rowstats":
+            tbuf = torch.zeros(((M + 255) // 256) * ((N + 255) // 256) * 8 * 8, device=dev)
             kw["stat_max"] = tbuf
 
         def run():
@@ -92,9 +92,13 @@ def main():
         if args.timing and "stat_max" in kw and epi != "rowstats":
             tb = kw["stat_max"].view(-1, 8).cpu()
             m = tb.mean(0)
-            steps = float(m[5])
-            print(f"   per-step ticks: mma {m[0] / steps:.1f} vmwait {m[6] / steps:.1f} barrier {m[1] / steps:.1f} "
-                  f"dma-issue {m[2] / steps:.1f} lgkm {m[3] / steps:.1f} total {m[4] / steps:.1f}")
+            if args.ring == 4:
+                steps = float(m[5])
+                print(f"   per-step ticks: mma {m[0] / steps:.1f} vmwait {m[6] / steps:.1f} barrier {m[1] / steps:.1f} "
+                      f"dma-issue {m[2] / steps:.1f} lgkm {m[3] / steps:.1f} total {m[4] / steps:.1f}")
+            else:
+                print(f"   per-workgroup ticks (100 MHz? see DESIGN): prologue {m[0]:.0f} main loop {m[1]:.0f} "
+                      f"({m[1] / max(float(m[3]), 1):.0f}/K-tile) epilogue {m[2]:.0f}")
         print(f"{name:10s} layout={layout} M={M:6d} N={N:6d} K={K:6d} {epi:8s} {us:9.1f} us  "
               f"{2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
 
