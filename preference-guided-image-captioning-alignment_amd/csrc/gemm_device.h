@@ -98,37 +98,63 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds, int wbase,
 // ---- epilogues ------------------------------------------------------------------------------------
 // Accumulator element acc[mi][ni][r] of wave (wm, wn) is C[m0 + wm*64 + mi*16 + (lane>>4)*4 + r]
 //                                                        [n0 + wn*64 + ni*16 + (lane&15)].
+// max / sum over the 16 lanes of a DPP row (the 16 columns a 16x16 MFMA tile gives one output row), every lane gets
+// the result.  quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: four VALU ops, no LDS crossbar
+// (`__shfl_xor` compiles to ds_bpermute: ~10x the latency, and the LM-head epilogue does 32 reductions per block).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+
 __device__ __forceinline__ void epilogue_rowstats(const pgca_gemm_args& a, f32x4 (&acc)[4][4], int m0, int n0, int tn,
                                                   int wm, int wn, int lane) {
   const int rbase = m0 + wm * 64 + (lane >> 4) * 4;
   const int cbase = n0 + wn * 64 + (lane & 15);
   const int part = (n0 >> 6) + wn;  // one partial per 64-column strip
+  // the 16 target ids of this lane's rows, requested before anything depends on them (one round trip, not 16)
+  long long tg[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rbase + mi * 16 + r;
+      tg[mi][r] = (row < a.M && a.targets) ? a.targets[row] : -1;
+    }
+  float bs[4];
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) bs[ni] = (a.bias && cbase + ni * 16 < a.N) ? a.bias[cbase + ni * 16] : 0.f;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = rbase + mi * 16 + r;
-      const long long tgt = (row < a.M && a.targets) ? a.targets[row] : -1;
-      float v0, v1, v2, v3;
-      {
-        float x[4];
+      const long long tgt = tg[mi][r];
+      float x[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          const int col = cbase + ni * 16;
-          float t = a.alpha * acc[mi][ni][r];
-          if (a.bias && col < a.N) t += a.bias[col];
-          if (col == tgt && a.target_val) a.target_val[row] = t;
-          x[ni] = col < a.N ? t : -INFINITY;
-        }
-        v0 = x[0]; v1 = x[1]; v2 = x[2]; v3 = x[3];
+      for (int ni = 0; ni < 4; ++ni) {
+        const int col = cbase + ni * 16;
+        const float t = a.alpha * acc[mi][ni][r] + bs[ni];
+        if (col == tgt && a.target_val) a.target_val[row] = t;
+        x[ni] = col < a.N ? t : -INFINITY;
       }
-      float mx = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float mx = row16_max(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
       float sm = 0.f;
-      if (mx > -INFINITY) sm = __expf(v0 - mx) + __expf(v1 - mx) + __expf(v2 - mx) + __expf(v3 - mx);
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o);
+      if (mx > -INFINITY) sm = __expf(x[0] - mx) + __expf(x[1] - mx) + __expf(x[2] - mx) + __expf(x[3] - mx);
+      sm = row16_sum(sm);
       if ((lane & 15) == 0 && row < a.M) {
         a.stat_max[(size_t)row * a.stat_ld + part] = mx;
         a.stat_sum[(size_t)row * a.stat_ld + part] = sm;
