@@ -366,7 +366,10 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       const int nkps = (nk_total + splits - 1) / splits;
       dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
       const int variant = plan_variant(a);
-      if (variant == 5) return launch_gemm_duo(b, nkps, (int)grid2.y, stream);
+      if (variant == 5) {
+        const int rc = launch_gemm_duo(b, nkps, (int)grid2.y, stream);
+        if (rc != 1) return rc;
+      }
       if (variant == 4) {
         const int rc = launch_gemm256w(b, ntm2, ntn2, nkps, (int)grid2.y, stream);
         if (rc != 1) return rc;  // 1: epilogue not implemented by the wide-wave kernel, use the 8-wave one

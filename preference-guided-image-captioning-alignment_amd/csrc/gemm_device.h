@@ -431,10 +431,12 @@ template <int EPI>
 __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int m0,
                                                int n0, int wm, int wn, int lane, int wave) {
   constexpr int LDC = 68;
-  if (epilogue_fast_ok<EPI>(a, m0 + wm * 64, n0 + wn * 64)) {  // wave-uniform
+  // residual / accumulate prefetch modes exist for the plain epilogue only (where the hot path uses them)
+  const bool rmw = a.residual || (a.out_f32 && a.accumulate);
+  if ((EPI == PGCA_EPI_NONE || !rmw) && epilogue_fast_ok<EPI>(a, m0 + wm * 64, n0 + wn * 64)) {  // wave-uniform
     const int mb = m0 + wm * 64, cb = n0 + wn * 64;
-    if (a.residual) epilogue_store_fast<EPI, PF_RES>(a, acc, smem, mb, cb, lane, wave);
-    else if (a.out_f32 && a.accumulate) epilogue_store_fast<EPI, PF_ACC>(a, acc, smem, mb, cb, lane, wave);
+    if (EPI == PGCA_EPI_NONE && a.residual) epilogue_store_fast<PGCA_EPI_NONE, PF_RES>(a, acc, smem, mb, cb, lane, wave);
+    else if (EPI == PGCA_EPI_NONE && rmw) epilogue_store_fast<PGCA_EPI_NONE, PF_ACC>(a, acc, smem, mb, cb, lane, wave);
     else epilogue_store_fast<EPI, PF_NONE>(a, acc, smem, mb, cb, lane, wave);
     // keep the block barriers of the general path below: other waves of the block may be on it
     __syncthreads();
@@ -507,6 +509,20 @@ __device__ __forceinline__ void run_epilogue(const pgca_gemm_args& a, f32x4 (&ac
     case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
   }
+}
+
+// Epilogues of the decoder trunk only - what the experimental tile variants (gemm_wide.hip, gemm_duo.hip) implement;
+// everything else falls back to gemm256_kernel.
+__device__ __forceinline__ void run_epilogue_trunk(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int mh,
+                                                   int n0, int wn, int lane, int wave) {
+  switch (a.epilogue) {
+    case PGCA_EPI_GELU_NEW: epilogue_store<PGCA_EPI_GELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_DGELU_NEW: epilogue_store<PGCA_EPI_DGELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+  }
+}
+__device__ __host__ __forceinline__ bool trunk_epilogue(int epi) {
+  return epi == PGCA_EPI_NONE || epi == PGCA_EPI_GELU_NEW || epi == PGCA_EPI_DGELU_NEW;
 }
 
 constexpr int BM2 = 256, BN2 = 256;

@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_duo_kernel(const pgca_gemm_args a
   }
   __syncthreads();  // the epilogue stages through the same LDS (4 waves x 8.5 KiB)
 
-  run_epilogue(a, acc[0], smemd, m0 + wm * 128, n0, tn, wn, lane, wave);
-  run_epilogue(a, acc[1], smemd, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
+  run_epilogue_trunk(a, acc[0], smemd, m0 + wm * 128, n0, wn, lane, wave);
+  run_epilogue_trunk(a, acc[1], smemd, m0 + wm * 128 + 64, n0, wn, lane, wave);
 }
 
 template <int LA, int LB>
@@ -202,7 +202,8 @@ int launch_duo(const pgca_gemm_args& a, int ntm, int ntn, int nkps, int nsplit, 
 
 int pgca::launch_gemm_duo(const pgca_gemm_args& a, int nk_per_split, int nsplit, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  const int ncols = a.epilogue == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
+  if (!trunk_epilogue(a.epilogue)) return 1;  // caller falls back to the 256^2 kernel
+  const int ncols = a.N;
   const int ntm = (a.M + DBM - 1) / DBM, ntn = (ncols + DBN - 1) / DBN;
   switch (a.layout) {
     case PGCA_NT: return launch_duo<0, 0>(a, ntm, ntn, nk_per_split, nsplit, s);

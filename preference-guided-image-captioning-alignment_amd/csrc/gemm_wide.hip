@@ -164,16 +164,6 @@ __device__ __forceinline__ void tile_step(f32x4 (&acc)[2][2][4][4], const u32x4 
 #undef PGCA_W_ROW
 }
 
-// Epilogues of the decoder trunk (the GEMMs this kernel is chosen for); the rest stay on the 8-wave kernel.
-__device__ __forceinline__ void run_epilogue_w(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int mh,
-                                               int n0, int wn, int lane, int wave) {
-  switch (a.epilogue) {
-    case PGCA_EPI_GELU_NEW: epilogue_store<PGCA_EPI_GELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_DGELU_NEW: epilogue_store<PGCA_EPI_DGELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-  }
-}
-
 #ifdef PGCA_GEMM_TIMING
 #define TSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
 #else
@@ -319,10 +309,10 @@ __global__ __launch_bounds__(256, 1) void gemm256w_kernel(const pgca_gemm_args a
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results (written from asm) settle before they are read
   __syncthreads();                                     // the epilogue stages through the same LDS
 
-  run_epilogue_w(a, acc[0][0], smemw, m0 + wm * 128, n0, wn * 2, lane, wave);
-  run_epilogue_w(a, acc[0][1], smemw, m0 + wm * 128, n0, wn * 2 + 1, lane, wave);
-  run_epilogue_w(a, acc[1][0], smemw, m0 + wm * 128 + 64, n0, wn * 2, lane, wave);
-  run_epilogue_w(a, acc[1][1], smemw, m0 + wm * 128 + 64, n0, wn * 2 + 1, lane, wave);
+  run_epilogue_trunk(a, acc[0][0], smemw, m0 + wm * 128, n0, wn * 2, lane, wave);
+  run_epilogue_trunk(a, acc[0][1], smemw, m0 + wm * 128, n0, wn * 2 + 1, lane, wave);
+  run_epilogue_trunk(a, acc[1][0], smemw, m0 + wm * 128 + 64, n0, wn * 2, lane, wave);
+  run_epilogue_trunk(a, acc[1][1], smemw, m0 + wm * 128 + 64, n0, wn * 2 + 1, lane, wave);
 }
 
 constexpr size_t GEMM256W_LDS = 2 * WSTAGES * WTILE;  // 128 KiB
@@ -347,7 +337,7 @@ int launch_one(const pgca_gemm_args& a, int ntm, int ntn, int nkps, int nsplit, 
 
 int pgca::launch_gemm256w(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int nsplit, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.epilogue != PGCA_EPI_NONE && a.epilogue != PGCA_EPI_GELU_NEW && a.epilogue != PGCA_EPI_DGELU_NEW) return 1;
+  if (!trunk_epilogue(a.epilogue)) return 1;
   switch (a.layout) {
     case PGCA_NT: return launch_one<0, 0>(a, ntm, ntn, nk_per_split, nsplit, s);
     case PGCA_NN: return launch_one<0, 1>(a, ntm, ntn, nk_per_split, nsplit, s);
