@@ -118,6 +118,21 @@ def cpu_baseline(model, arch, S, beta, pairs):
                       f"oracle/restatement.py; {dt:.1f} s"}
 
 
+def traffic_from_profile(pairs_per_gpu: int):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    cannot be collected inside this process; tools/pmc_traffic.py turns the two passes of THIS command into
+    profiles/r01_gemm_traffic.json).  Only reported for the workload the passes were taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d.get("pairs_per_gpu") != pairs_per_gpu:
+            return None
+        return float(d["dominant"]["hbm_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,7 +144,7 @@ def main():
     ap.add_argument("--text-model", default="gpt2-medium")
     ap.add_argument("--reference-free", action="store_true", help="2-forward trainer path instead of 4-forward DPO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=8)
+    ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout of the policy (reference: 0.1)")
     args = ap.parse_args()
@@ -237,7 +252,9 @@ def main():
         ps = probe.summary()
         if ps:
             res["roofline"] = {"bound": "mfma", "achieved": ps["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ps["tflops"] / PEAK_BF16_TFLOPS, "traffic": None,
+                               "frac": ps["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic_from_profile(B),
+                               "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                                               "gfx950 FETCH x2 correction) of this command: profiles/r01_gemm_traffic.json",
                                "kernel": "gemm256_kernel<0, 1> (every launch of the NN 256x256 LDS-DMA GEMM, 2-stage schedule, in the timed steps)", "launches": ps["launches"],
                                "avg_launch_us": ps["avg_us"]}
         if dp.world == 1 and not args.no_cpu_baseline:
