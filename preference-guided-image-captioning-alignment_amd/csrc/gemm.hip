@@ -295,10 +295,14 @@ int plan_tile(const pgca_gemm_args& a, int* splits_out) {
 // the default in isolation and equal end to end and were removed; DESIGN.md section 5 has the numbers.
 static int plan_variant(const pgca_gemm_args& a) {
   const char* env = getenv("PGCA_GEMM_RING");
-  (void)a;
-  if (env && atoi(env) == 4) return 4;
-  if (env && atoi(env) == 5) return 5;
-  return 0;
+  if (env) {
+    const int v = atoi(env);
+    return (v == 4 || v == 5 || v == 6) ? v : 0;
+  }
+  // K-contiguous A (forward, data gradients, LM head): the phase-staggered loop (gemm_phase.hip) is 3-12 % faster;
+  // the K-strided weight-gradient layout pays two transposed LDS reads per fragment in the load phases and stays
+  // on the plain 2-stage loop.
+  return a.layout == PGCA_TN ? 0 : 6;
 }
 
 extern "C" int pgca_gemm_plan(const pgca_gemm_args* args) {
@@ -366,6 +370,7 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       const int nkps = (nk_total + splits - 1) / splits;
       dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
       const int variant = plan_variant(a);
+      if (variant == 6) return launch_gemm256s(b, ntm2, ntn2, nkps, (int)grid2.y, stream);
       if (variant == 5) {
         const int rc = launch_gemm_duo(b, nkps, (int)grid2.y, stream);
         if (rc != 1) return rc;

@@ -12,6 +12,8 @@ namespace pgca {
 int launch_gemm256w(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int nsplit, void* stream);
 // 256 x 128 tile, 4 waves, two workgroups per CU (gemm_duo.hip).  nk_per_split in 64-deep tiles.
 int launch_gemm_duo(const pgca_gemm_args& a, int nk_per_split, int nsplit, void* stream);
+// 256 x 256, 8 waves, phase-staggered wave groups, 4-stage BK=32 ring (gemm_phase.hip).
+int launch_gemm256s(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int nsplit, void* stream);
 }  // namespace pgca
 
 using namespace pgca;

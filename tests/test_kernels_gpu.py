@@ -50,13 +50,13 @@ SHAPES = [(128, 128, 64), (256, 384, 1024), (200, 136, 72), (77, 1000, 128), (1,
           (512, 768, 256), (300, 520, 192), (1000, 1000, 64)]
 
 
-@pytest.fixture(params=[128, 256, 260, 261])
+@pytest.fixture(params=[128, 256, 260, 261, 262])
 def tile(request):
     """Force the 128^2 register-staged kernel, the 256^2 LDS-DMA kernel with the 2-stage BK=64 loop (256) or
     its 4-stage BK=32 ring (257).  The 256^2 kernels need K % 64 == 0."""
     import os
     os.environ["PGCA_GEMM_TILE"] = "128" if request.param == 128 else "256"
-    os.environ["PGCA_GEMM_RING"] = {260: "4", 261: "5"}.get(request.param, "0")   # 260: wide-wave (gemm_wide.hip), 261: duo 256x128 (gemm_duo.hip)
+    os.environ["PGCA_GEMM_RING"] = {260: "4", 261: "5", 262: "6"}.get(request.param, "0")   # 260: wide-wave (gemm_wide.hip), 261: duo 256x128 (gemm_duo.hip)
     yield 256 if request.param > 256 else request.param
     os.environ.pop("PGCA_GEMM_TILE", None)
     os.environ.pop("PGCA_GEMM_RING", None)
