@@ -52,8 +52,9 @@ class GemmProbe:
         self.layout, self.events, self.enabled = layout, [], False
 
     def want(self, layout, epilogue, plan):
-        # plan = schedule*1e6 + tile*100 + splits: keep launches of gemm256_kernel<0,1> (schedule 0, tile 256)
-        return self.enabled and layout == self.layout and plan // 100 == 256
+        # plan = schedule*1e6 + tile*100 + splits: keep launches of gemm256s_kernel<0,1> (schedule 6 = the
+        # phase-staggered loop the NN layout runs by default, tile 256)
+        return self.enabled and layout == self.layout and plan // 100 == 60256
 
     def add(self, e0, e1, flops):
         self.events.append((e0, e1, flops))
@@ -255,7 +256,7 @@ def main():
                                "frac": ps["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic_from_profile(B),
                                "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                                                "gfx950 FETCH x2 correction) of this command: profiles/r01_gemm_traffic.json",
-                               "kernel": "gemm256_kernel<0, 1> (every launch of the NN 256x256 LDS-DMA GEMM, 2-stage schedule, in the timed steps)", "launches": ps["launches"],
+                               "kernel": "gemm256s_kernel<0, 1> (every launch of the NN 256x256 LDS-DMA GEMM, phase-staggered schedule, in the timed steps)", "launches": ps["launches"],
                                "avg_launch_us": ps["avg_us"]}
         if dp.world == 1 and not args.no_cpu_baseline:
             hip.gemm_probe = None

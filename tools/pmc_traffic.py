@@ -39,7 +39,7 @@ def main():
     ap.add_argument("fetch_dir")
     ap.add_argument("write_dir")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--match", default="gemm256_kernel<0, 1>")
+    ap.add_argument("--match", default="gemm256s_kernel<0, 1>")
     a = ap.parse_args()
     fe, wr = per_kernel(a.fetch_dir, "FETCH_SIZE"), per_kernel(a.write_dir, "WRITE_SIZE")
     rows = []
