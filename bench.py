@@ -258,6 +258,29 @@ def main():
                                                "gfx950 FETCH x2 correction) of this command: profiles/r01_gemm_traffic.json",
                                "kernel": "gemm256s_kernel<0, 1> (every launch of the NN 256x256 LDS-DMA GEMM, phase-staggered schedule, in the timed steps)", "launches": ps["launches"],
                                "avg_launch_us": ps["avg_us"]}
+        if ps and dp.world == 1:
+            # measured ceiling beside the vendor peak: the library GEMM on this GPU, outside the timed region.
+            # Yardstick only - nothing in the product path calls a BLAS library.
+            try:
+                n = 8192
+                xa = (torch.rand(n, n, device=dev) * 2 - 1).bfloat16()
+                xb = (torch.rand(n, n, device=dev) * 2 - 1).bfloat16()
+                for _ in range(2):
+                    torch.matmul(xa, xb)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    torch.matmul(xa, xb)
+                e1.record()
+                torch.cuda.synchronize()
+                lib = 10 * 2.0 * n ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+                res["roofline"]["library_ceiling_tflops"] = lib
+                res["roofline"]["frac_of_library_ceiling"] = ps["tflops"] / lib
+                res["roofline"]["library_ceiling_note"] = "torch.matmul bf16 8192^3 (hipBLASLt), random operands, same GPU"
+                del xa, xb
+            except Exception as exc:  # noqa: BLE001 - a missing BLAS must not break the bench line
+                res["roofline"]["library_ceiling_note"] = f"unavailable: {exc}"
         if dp.world == 1 and not args.no_cpu_baseline:
             hip.gemm_probe = None
             log("cpu baseline (oracle on host cores) ...")
