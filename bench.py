@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout of the policy (reference: 0.1)")
+    ap.add_argument("--stage", type=int, default=2, choices=(1, 2),
+                    help="2 (default): the headline Stage-2 DPO step; 1: secondary line, Stage-1 NT-Xent step "
+                         "(global negatives over the ranks when N > 1)")
     args = ap.parse_args()
 
     from pgca_amd import hip
@@ -155,7 +158,7 @@ def main():
     from pgca_amd.dist import DataParallel, OverlappedTrunkReducer
     from pgca_amd.engine import DropoutPlan
     from pgca_amd.model import PreferenceGuidedCaptioningModel
-    from pgca_amd.steps import DPOStep, FusedOptimizer, ReferencePolicy
+    from pgca_amd.steps import ContrastiveStep, DPOStep, FusedOptimizer, ReferencePolicy
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -174,36 +177,58 @@ def main():
     arch = make_arch(args.vision_model, args.text_model, 512)
     model = PreferenceGuidedCaptioningModel(args.vision_model, args.text_model, 512, temperature=0.5,
                                             freeze_vision_backbone=True, device=dev, seed=42)
-    ref = None if args.reference_free else ReferencePolicy(model.store, model.ws)
-    step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
-                   model.caption_decoder.engine, beta=beta, reference_free=args.reference_free, ref=ref,
-                   dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
-    segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
-    opt = FusedOptimizer(segs, lr=1e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=500,
+    stage1 = args.stage == 1
+    if stage1:
+        ref = None
+        step = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                               model.text_encoder.engine, temperature=0.5, dp=dp, global_negatives=True,
+                               dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
+        segs = [model.store.segments["vision_head"], model.store.segments["text_head"],
+                model.store.segments["text_tower"]]
+        trunk = model.text_encoder.engine.trunk
+    else:
+        ref = None if args.reference_free else ReferencePolicy(model.store, model.ws)
+        step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                       model.caption_decoder.engine, beta=beta, reference_free=args.reference_free, ref=ref,
+                       dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
+        segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
+        trunk = model.caption_decoder.engine.trunk
+    opt = FusedOptimizer(segs, lr=5e-5 if stage1 else 1e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=500,
                          total_steps=100000, sched_stride=dp.world)
-    reducer = OverlappedTrunkReducer(dp, model.caption_decoder.engine.trunk, group=4)
+    reducer = OverlappedTrunkReducer(dp, trunk, group=4)
     reducer.arm()
     log(f"model + optimizer ready ({model.store.num_params() / 1e6:.1f} M params)")
 
     nbatch = 4  # distinct resident batches, cycled
-    batches = [DPOStep.prepare(synthetic_batch(B, S, arch.gpt.base_vocab, arch.gpt.base_vocab,
-                                               seed=1234 + dp.rank + 1000 * i), dev) for i in range(nbatch)]
+    raw = [synthetic_batch(B, S, arch.gpt.base_vocab, arch.gpt.base_vocab, seed=1234 + dp.rank + 1000 * i)
+           for i in range(nbatch)]
+    if stage1:
+        batches = [ContrastiveStep.prepare({"image": r["image"], "caption_ids": r["preferred_ids"],
+                                            "caption_mask": r["preferred_mask"]}, dev) for r in raw]
+    else:
+        batches = [DPOStep.prepare(r, dev) for r in raw]
+    del raw
     probe = GemmProbe(hip.NN)
     if not args.no_probe and dp.rank == 0:
         hip.gemm_probe = probe
 
+    last = [None]
+
     def one_step(i):
         p = batches[i % nbatch]
         opt.zero_grad()
-        step.loss_and_grads(p["image"], p["seq"])
-        reducer.finish(other_segments=[segs[0]])
+        if stage1:
+            last[0] = step.loss_and_grads(p["image"], p["ids"], p["mask"])
+        else:
+            last[0] = step.loss_and_grads(p["image"], p["seq"])
+        reducer.finish(other_segments=segs[:-1])
         opt.step(grad_scale=1.0 / dp.world)
 
     log("batches resident; warm-up")
     for i in range(args.warmup):
         one_step(i)
         torch.cuda.synchronize()
-        log(f"warm-up step {i} done, loss={float(step.loss):.5f}")
+        log(f"warm-up step {i} done, loss={float(last[0]):.5f}")
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -218,7 +243,7 @@ def main():
     probe.enabled = False
     dt = dp.all_reduce_max_scalar(dt, dev)
     log(f"timed region: {args.steps} steps in {dt:.3f} s -> {B * dp.world * args.steps / dt:.1f} pairs/s")
-    loss_val = float(step.loss)
+    loss_val = float(last[0])
     st = opt.state()
 
     if dp.rank == 0:
@@ -232,15 +257,21 @@ def main():
             + 2 * v.patch_dim * v.hidden * (v.tokens - 1)
         n_fwd = 6 if args.reference_free else 8      # policy 2 x (fwd + 2 bwd) [+ reference 2 x fwd]
         flop_pair = n_fwd * seq_fwd + vit_fwd
+        if stage1:  # text tower without LM head, fwd + 2 x bwd, one ViT forward (245.6 GFLOP/pair)
+            flop_pair = 3 * (24 * g.hidden ** 2 * g.layers + 4 * S * g.hidden * g.layers) * S + vit_fwd
         res = {
-            "metric": "DPO preference-pairs/sec, CLIP-ViT-B/32+GPT-2-M seq128",
+            "metric": ("Stage-1 NT-Xent image-caption pairs/sec, CLIP-ViT-B/32+GPT-2-M seq128 (secondary)" if stage1
+                       else "DPO preference-pairs/sec, CLIP-ViT-B/32+GPT-2-M seq128"),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": ("Stage-2 DPO step, " + ("2-forward reference-free" if args.reference_free
+            "config": {"workload": (("Stage-1 NT-Xent step (tau 0.5, global negatives over the ranks), "
+                                     f"{args.vision_model} (frozen) + {args.text_model} text tower, seq_len {S}, "
+                                     "bf16 MFMA / f32 accumulate+master, AdamW+clip") if stage1 else
+                                    ("Stage-2 DPO step, " + ("2-forward reference-free" if args.reference_free
                                                              else "4-forward policy/reference x chosen/rejected")
-                                    + f", {args.vision_model} (frozen) + {args.text_model} decoder, seq_len {S}, "
-                                    "beta 0.1, bf16 MFMA / f32 accumulate+master, AdamW+clip"),
+                                     + f", {args.vision_model} (frozen) + {args.text_model} decoder, seq_len {S}, "
+                                     "beta 0.1, bf16 MFMA / f32 accumulate+master, AdamW+clip")),
                        "pairs_per_gpu": B, "global_pairs_per_step": B * dp.world, "seq_len": S,
                        "parallelism": f"dp{dp.world}",
                        "dropout": (f"train mode, p={args.dropout} at the reference's sites (fused, counter-based, "
@@ -281,7 +312,7 @@ def main():
                 del xa, xb
             except Exception as exc:  # noqa: BLE001 - a missing BLAS must not break the bench line
                 res["roofline"]["library_ceiling_note"] = f"unavailable: {exc}"
-        if dp.world == 1 and not args.no_cpu_baseline:
+        if dp.world == 1 and not args.no_cpu_baseline and not stage1:
             hip.gemm_probe = None
             log("cpu baseline (oracle on host cores) ...")
             res["cpu_baseline"] = cpu_baseline(model, arch, S, beta, args.cpu_pairs)
