@@ -559,3 +559,34 @@ def test_embed_train_mode_heads_and_dropout(hip):
     close(dwpe, pr.grad, 3e-5, "dwpe")
     close(dU, Ur.grad, 3e-5, "dU")
     close(datt.sum(0), br.grad, 3e-5, "d b_o")
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("shape", [(2048, 1024, 1024), (1536, 768, 4096), (4096, 512, 256), (1000, 520, 192)])
+def test_phase_staggered_gemm_race_screen(hip, layout, shape):
+    """The phase-staggered loop (gemm_phase.hip) orders its LDS-DMA, fragment reads and barriers by count, two wave
+    groups one barrier apart.  A mis-placed wait shows up as rare wrong tiles, so: 25 launches per shape, each
+    compared BITWISE with the plain 2-stage kernel (same K order per output element -> identical f32 results)."""
+    import os
+    M, N, K = shape
+    a, b, A, B = operands(layout, M, N, K, seed=layout * 7 + K)
+    ldb = None
+    if layout != 0 and N % 8:
+        ldn = (N + 7) // 8 * 8
+        Bp = torch.zeros(K, ldn, dtype=torch.bfloat16, device=dev())
+        Bp[:, :N] = b
+        B, ldb = Bp, ldn
+    os.environ["PGCA_GEMM_TILE"] = "256"
+    try:
+        os.environ["PGCA_GEMM_RING"] = "0"
+        want = torch.zeros(M, N, device=dev())
+        hip.gemm(A, B, M, N, K, layout, ldb=ldb, out_f32=want)
+        close(want, a.float() @ b.float(), 2e-4, "2-stage kernel")
+        os.environ["PGCA_GEMM_RING"] = "6"
+        for it in range(25):
+            got = torch.full((M, N), float("nan"), device=dev())
+            hip.gemm(A, B, M, N, K, layout, ldb=ldb, out_f32=got)
+            assert torch.equal(got, want), f"launch {it}: {(got != want).sum().item()} elements differ"
+    finally:
+        os.environ.pop("PGCA_GEMM_TILE", None)
+        os.environ.pop("PGCA_GEMM_RING", None)
