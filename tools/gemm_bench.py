@@ -75,6 +75,7 @@ def main():
         if args.timing and epi != "rowstats":
             tbuf = torch.zeros(((M + 255) // 256) * ((N + 255) // 256) * 8 * 8, device=dev)
             kw["stat_max"] = tbuf
+            kw["stat_sum"] = torch.zeros_like(tbuf)
 
         def run():
             hip.gemm(A, B, M, N, K, layout, **kw)
@@ -97,6 +98,12 @@ def main():
                 print(f"   per-step ticks: mma {m[0] / steps:.1f} vmwait {m[6] / steps:.1f} barrier {m[1] / steps:.1f} "
                       f"dma-issue {m[2] / steps:.1f} lgkm {m[3] / steps:.1f} total {m[4] / steps:.1f}")
             else:
+                ph = kw["stat_sum"].view(-1, 8).cpu()
+                if float(ph.abs().sum()) > 0:  # gemm_phase.o built with -DPGCA_GEMM_TIMING2
+                    g0, g1 = ph.view(-1, 8, 8)[:, :4].mean((0, 1)), ph.view(-1, 8, 8)[:, 4:].mean((0, 1))
+                    names = ["L0", "B1+w", "M0", "B2", "L1", "B1'+w", "M1", "B2'"]
+                    print("   phase clocks per 32-deep tile  group0: " + " ".join(f"{n} {x:.0f}" for n, x in zip(names, g0)))
+                    print("                                  group1: " + " ".join(f"{n} {x:.0f}" for n, x in zip(names, g1)))
                 print(f"   per-workgroup ticks (100 MHz? see DESIGN): prologue {m[0]:.0f} main loop {m[1]:.0f} "
                       f"({m[1] / max(float(m[3]), 1):.0f}/K-tile) epilogue {m[2]:.0f}")
         print(f"{name:10s} layout={layout} M={M:6d} N={N:6d} K={K:6d} {epi:8s} {us:9.1f} us  "
