@@ -76,6 +76,13 @@ __device__ __forceinline__ void wait_vm_p() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// -DPGCA_GEMM_TIMING: main-loop / epilogue clocks per workgroup; -DPGCA_GEMM_TIMING2 adds per-phase clocks
+// (tools/gemm_bench.py --timing reads them from the stat_max / stat_sum buffers).  Stamps cost a lgkmcnt(0) each.
+#ifdef PGCA_GEMM_TIMING2
+#define PSTAMP(v) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v)::"memory")
+#else
+#define PSTAMP(v)
+#endif
 #define PGCA_PBAR()                       \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -147,7 +154,16 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
   PGCA_PBAR();                 // second barrier: same distance (two) as in the steady state
   if (wm == 1) PGCA_PBAR();    // group 1 runs one barrier late from here on
 
+#ifdef PGCA_GEMM_TIMING
+  unsigned long long ts1, ts2, ts3;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts1)::"memory");
+#endif
+#ifdef PGCA_GEMM_TIMING2
+  unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0, q8 = 0;
+  unsigned long long aL0 = 0, aB1 = 0, aM0 = 0, aB2 = 0, aL1 = 0, aB3 = 0, aM1 = 0, aB4 = 0;
+#endif
   for (int kt = 0; kt < nk; ++kt) {
+    PSTAMP(q0);
     const unsigned char* la = smems + (kt & 3) * 2 * PTILE_BYTES;
     const unsigned char* lb = la + PTILE_BYTES;
     bf16x8 fa[4], fb[4];
@@ -159,9 +175,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
     __builtin_amdgcn_sched_barrier(0);
     if (kt >= 1 && kt + 2 < nk) db.issue(bbase + (size_t)(kt + 2) * bstep, smems + ((kt + 2) & 3) * 2 * PTILE_BYTES + PTILE_BYTES, wave);
     if (kt == 0 && 2 < nk) db.issue(bbase + 2 * bstep, smems + 5 * PTILE_BYTES, wave);
+    PSTAMP(q1);
     PGCA_PBAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // after the barrier: the fragment latency hides in the barrier wait
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(q2);
     // ---------------- M0
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -169,7 +187,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[0][i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    PSTAMP(q3);
     PGCA_PBAR();
+    PSTAMP(q4);
     // ---------------- L1: A rows 64-127; A pieces of tile kt+3; retire tile kt+1
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[i] = read_frag_p<LA>(la, wm * 128 + 64, i, lane);
@@ -182,9 +202,11 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
     } else {
       wait_vm_p<0>();
     }
+    PSTAMP(q5);
     PGCA_PBAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(q6);
     // ---------------- M1
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -192,13 +214,37 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[1][i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    PSTAMP(q7);
     PGCA_PBAR();
+    PSTAMP(q8);
+#ifdef PGCA_GEMM_TIMING2
+    aL0 += q1 - q0; aB1 += q2 - q1; aM0 += q3 - q2; aB2 += q4 - q3;
+    aL1 += q5 - q4; aB3 += q6 - q5; aM1 += q7 - q6; aB4 += q8 - q7;
+#endif
   }
+#ifdef PGCA_GEMM_TIMING2
+  if (a.stat_sum && a.epilogue != PGCA_EPI_ROWSTATS && lane == 0) {
+    float* o = a.stat_sum + ((size_t)blockIdx.x * 8 + wave) * 8;
+    const float inv = 1.f / (float)nk;
+    o[0] = aL0 * inv; o[1] = aB1 * inv; o[2] = aM0 * inv; o[3] = aB2 * inv;
+    o[4] = aL1 * inv; o[5] = aB3 * inv; o[6] = aM1 * inv; o[7] = aB4 * inv;
+  }
+#endif
   if (wm == 0) PGCA_PBAR();  // re-join the groups
   __syncthreads();           // the epilogue stages through the same LDS
 
+#ifdef PGCA_GEMM_TIMING
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts2)::"memory");
+#endif
   run_epilogue(a, acc[0], smems, m0 + wm * 128, n0, tn, wn, lane, wave);
   run_epilogue(a, acc[1], smems, m0 + wm * 128 + 64, n0, tn, wn, lane, wave);
+#ifdef PGCA_GEMM_TIMING
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts3)::"memory");
+  if (a.stat_max && a.epilogue != PGCA_EPI_ROWSTATS && lane == 0) {
+    float* o = a.stat_max + ((size_t)blockIdx.x * 8 + wave) * 8;
+    o[0] = 0.f; o[1] = (float)(ts2 - ts1); o[2] = (float)(ts3 - ts2); o[3] = (float)(nk / 2);
+  }
+#endif
 }
 
 constexpr size_t GEMM256S_LDS = (size_t)2 * PSTAGES * PTILE_BYTES;  // 128 KiB
