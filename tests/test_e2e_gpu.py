@@ -186,13 +186,16 @@ def test_optimizer_step_changes_only_trainable_segments(tiny):
         s.ensure_bf16()
 
 
-def test_config2_geometry_against_oracle():
+@pytest.mark.parametrize("text_model", ["gpt2-medium", "gpt2-large", "gpt2-xl"])
+def test_config2_geometry_against_oracle(text_model):
     """ViT-B/32 + GPT-2-M widths at S = 128 with 2 layers each (full depth is the bench's job):
-    fused log-probs, DPO loss and gradients vs the CPU restatement on identical weights/batch."""
+    fused log-probs, DPO loss and gradients vs the CPU restatement on identical weights/batch.
+    gpt2-large / gpt2-xl: the decoder widths of configs C4 / C5 (1280 x 20 heads, 1600 x 25 heads) through the same
+    kernels (LayerNorm NV = 5 / 7, K = 1280 / 1600 / 5120 / 6400 GEMMs, 200-wide cross-attention heads)."""
     from pgca_amd.arch import make_arch, with_layers
     from pgca_amd.model import PreferenceGuidedCaptioningModel
     from pgca_amd.steps import DPOStep
-    arch = with_layers(make_arch("openai/clip-vit-base-patch32", "gpt2-medium", 512), 2, 2)
+    arch = with_layers(make_arch("openai/clip-vit-base-patch32", text_model, 512), 2, 2)
     model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=arch, seed=7, device="cuda:0")
     gen = torch.Generator().manual_seed(1234)
     B, S = 2, 128
