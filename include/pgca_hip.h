@@ -102,8 +102,10 @@ typedef struct pgca_gemm_args {
 
 int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
 /* Which kernel pgca_gemm_bf16 would launch for these arguments: schedule*1000000 + tile*100 + K-splits
- * (12801 = general 128^2 register-staged kernel; 256xx = 256^2 LDS-DMA kernel with xx K-splits, schedule
- * 0 = 2-stage BK=64 loop (gemm256_kernel), 1 = ring, 2 = phased, 3 = phased ring (gemm256q_kernel)). */
+ * (12801 = general 128^2 register-staged kernel; 256xx = 256^2 LDS-DMA tile with xx K-splits; schedule
+ * 0 = 2-stage BK=64 loop (gemm256_kernel, default for the K-strided TN layout), 6 = phase-staggered 4-stage BK=32
+ * loop (gemm256s_kernel, default for NT / NN); experimental, selected with PGCA_GEMM_RING: 4 = wide-wave
+ * (gemm256w_kernel), 5 = 256x128 two-workgroups-per-CU (gemm_duo_kernel)). */
 int pgca_gemm_plan(const pgca_gemm_args* args);
 
 /* Per-row combine of ROWSTATS partials: lse[m] = log sum exp over all columns;
