@@ -107,6 +107,11 @@ int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
  * loop (gemm256s_kernel, default for NT / NN); experimental, selected with PGCA_GEMM_RING: 4 = wide-wave
  * (gemm256w_kernel), 5 = 256x128 two-workgroups-per-CU (gemm_duo_kernel)). */
 int pgca_gemm_plan(const pgca_gemm_args* args);
+/* `count` GEMMs in one launch.  Up to four TN problems with epilogue NONE and an f32 (accumulating) output - the four
+ * weight gradients of one GPT-2 block (autograd of Conv1D c_attn / c_proj / c_fc / mlp.c_proj, reference
+ * modeling_gpt2.py:203,222-224,229-243 under trainer.py:494,606 loss.backward()) - run as ONE grid with the whole K per
+ * tile: no split-K, no atomics.  Anything else falls back to `count` ordinary pgca_gemm_bf16 launches. */
+int pgca_gemm_bf16_grouped(const pgca_gemm_args* args, int32_t count, void* stream);
 
 /* Per-row combine of ROWSTATS partials: lse[m] = log sum exp over all columns;
  * out_logprob[m] = target_val[m] - lse[m] (token log-prob, reference model.py:1074-1079). */

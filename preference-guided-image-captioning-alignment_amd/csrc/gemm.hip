@@ -148,11 +148,10 @@ __global__ void rowstats_combine_kernel(const float* __restrict__ smax, const fl
 // row/column (clamped rows only feed outputs the epilogue masks), K must be a multiple of 64.
 // ================================================================================================
 template <int LA, int LB>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];  // [2 stages][A | B][32 KiB]
-
+__device__ __forceinline__ void gemm256_body(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int bid_in,
+                                             int ksplit, unsigned char* smem2) {  // smem2: [2 stages][A | B][32 KiB]
   const int nwg = ntm * ntn;
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a,
       for (int j = 0; j < 4; ++j) acc[h][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // split-K: blockIdx.y owns K tiles [kt0, kt0 + nk) and adds its partial with f32 atomics (accumulate == 2)
-  const int kt0 = blockIdx.y * nk_per_split;
+  const int kt0 = ksplit * nk_per_split;
   const int nk = min(nk_per_split, a.K / BK - kt0);
   abase += (size_t)kt0 * astep;
   bbase += (size_t)kt0 * bstep;
@@ -244,6 +243,53 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a,
 #endif
 }
 
+template <int LA, int LB>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  gemm256_body<LA, LB>(a, ntm, ntn, nk_per_split, blockIdx.x, blockIdx.y, smem2);
+}
+
+// Grouped launch of up to four TN (weight-gradient) problems: C_p (+)= A_p^t B_p.  One decoder layer has four weight
+// gradients with 16-64 output tiles each; launched one by one each needs split-K to fill 256 CUs and then pays
+// 4 x M x N f32 atomics (memory-side, 1.3 TB/s chip-wide: ~48 us per launch).  Together they are 192 tiles with the
+// whole K each: no split, no atomics, a plain read-modify-write epilogue.
+struct pgca_group_param {
+  pgca_gemm_args a[4];
+  int start[5];  // first workgroup of problem p; start[count..4] = total
+  int ntm[4], ntn[4];
+};
+
+__global__ __launch_bounds__(512, 2) void gemm256_group_tn_kernel(const pgca_group_param gp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+  const int b = blockIdx.x;
+  int p = 0;
+  if (b >= gp.start[1]) p = 1;
+  if (b >= gp.start[2]) p = 2;
+  if (b >= gp.start[3]) p = 3;
+  // field-by-field selection with constant indices keeps everything in SGPRs (a dynamically indexed by-value
+  // aggregate would be spilled to scratch and come back in VGPRs, which the LDS-DMA asm cannot take)
+#define PGCA_SEL(F) (p == 0 ? gp.a[0].F : p == 1 ? gp.a[1].F : p == 2 ? gp.a[2].F : gp.a[3].F)
+  pgca_gemm_args a = {};
+  a.A = PGCA_SEL(A);
+  a.B = PGCA_SEL(B);
+  a.M = PGCA_SEL(M);
+  a.N = PGCA_SEL(N);
+  a.K = PGCA_SEL(K);
+  a.lda = PGCA_SEL(lda);
+  a.ldb = PGCA_SEL(ldb);
+  a.out_f32 = PGCA_SEL(out_f32);
+  a.ld_out_f32 = PGCA_SEL(ld_out_f32);
+  a.alpha = PGCA_SEL(alpha);
+  a.accumulate = PGCA_SEL(accumulate);
+  a.layout = PGCA_TN;
+  a.epilogue = PGCA_EPI_NONE;
+#undef PGCA_SEL
+  const int ntm = p == 0 ? gp.ntm[0] : p == 1 ? gp.ntm[1] : p == 2 ? gp.ntm[2] : gp.ntm[3];
+  const int ntn = p == 0 ? gp.ntn[0] : p == 1 ? gp.ntn[1] : p == 2 ? gp.ntn[2] : gp.ntn[3];
+  const int st = p == 0 ? gp.start[0] : p == 1 ? gp.start[1] : p == 2 ? gp.start[2] : gp.start[3];
+  gemm256_body<1, 1>(a, ntm, ntn, a.K / BK, b - st, 0, smem2);
+}
+
 constexpr size_t GEMM256_LDS = 4 * TILE2_BYTES;  // 128 KiB
 
 int ensure_gemm256_attr() {
@@ -255,7 +301,9 @@ int ensure_gemm256_attr() {
                                         (int)GEMM256_LDS);
     hipError_t e3 = hipFuncSetAttribute((const void*)gemm256_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GEMM256_LDS);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+    hipError_t e4 = hipFuncSetAttribute((const void*)gemm256_group_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)GEMM256_LDS);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
       (void)hipGetLastError();
       set_error("gemm256: cannot raise dynamic LDS limit");
       return PGCA_ERR_LAUNCH;
@@ -397,6 +445,47 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
     default: set_error("pgca_gemm_bf16: unknown layout %d", a.layout); return PGCA_ERR_INVALID;
   }
   return check_launch("pgca_gemm_bf16");
+}
+
+extern "C" int pgca_gemm_bf16_grouped(const pgca_gemm_args* args, int32_t count, void* stream) {
+  if (!args || count <= 0) {
+    set_error("pgca_gemm_bf16_grouped: no problems");
+    return PGCA_ERR_INVALID;
+  }
+  bool groupable = count <= 4 && !getenv("PGCA_GEMM_NO_GROUP");
+  for (int i = 0; i < count && groupable; ++i) {
+    const pgca_gemm_args& a = args[i];
+    groupable = a.layout == PGCA_TN && a.A && a.B && a.K > 0 && (a.K % BK) == 0 && a.M >= 8 && a.N >= 8 &&
+                a.epilogue == PGCA_EPI_NONE && a.out_f32 && !a.out_bf16 && !a.bias && !a.residual &&
+                !a.drop_threshold && !(a.lda & 7) && !(a.ldb & 7) && !((uintptr_t)a.A & 15) && !((uintptr_t)a.B & 15) &&
+                a.lda >= ((a.M + 7) & ~7) && a.ldb >= ((a.N + 7) & ~7);
+  }
+  if (!groupable) {  // anything else: the ordinary path, one launch per problem
+    for (int i = 0; i < count; ++i) {
+      const int rc = pgca_gemm_bf16(&args[i], stream);
+      if (rc) return rc;
+    }
+    return PGCA_OK;
+  }
+  if (ensure_gemm256_attr()) return PGCA_ERR_LAUNCH;
+  pgca_group_param gp;
+  int total = 0;
+  for (int i = 0; i < 4; ++i) {
+    if (i < count) {
+      gp.a[i] = args[i];
+      gp.ntm[i] = (args[i].M + BM2 - 1) / BM2;
+      gp.ntn[i] = (args[i].N + BN2 - 1) / BN2;
+      gp.start[i] = total;
+      total += gp.ntm[i] * gp.ntn[i];
+    } else {
+      gp.a[i] = args[count - 1];
+      gp.ntm[i] = gp.ntn[i] = 1;
+      gp.start[i] = 0x7fffffff;
+    }
+  }
+  gp.start[4] = total;
+  hipLaunchKernelGGL(gemm256_group_tn_kernel, dim3(total), dim3(512), GEMM256_LDS, (hipStream_t)stream, gp);
+  return check_launch("pgca_gemm_bf16_grouped");
 }
 
 extern "C" int pgca_rowstats_combine(const float* stat_max, const float* stat_sum, int32_t stat_ld, int32_t nparts,

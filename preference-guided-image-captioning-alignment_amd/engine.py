@@ -254,10 +254,10 @@ class GptTrunk:
             # ---- MLP: h_out = hm + c_proj(gelu(c_fc(ln2(hm))))
             dpre = self._buf("dpre", (M, I), BF16)
             hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=s["pre"], out_bf16=dpre)
-            hip.gemm(s["act"], g_bf, I, H, M, hip.TN, lda=I, ldb=H, out_f32=P["wpr"].g, accumulate=True)
+            wgrads = [(s["act"], g_bf, I, H, M, P["wpr"].g)]   # the layer's four weight gradients go out together
             dln = self._buf("dln", (M, H), BF16)
             hip.gemm(dpre, P["wfc"].b, M, H, I, hip.NT, out_bf16=dln)
-            hip.gemm(s["ln2"], dpre, H, I, M, hip.TN, lda=H, ldb=I, out_f32=P["wfc"].g, accumulate=True)
+            wgrads.append((s["ln2"], dpre, H, I, M, P["wfc"].g))
             _bias_grad(ws, M, I, I, P["bfc"].g, x_bf16=dpre)
             g2 = self._buf("g_b" if (li & 1) else "g_a", (M, H), F32)
             g2_bf = self._buf("gbf_b" if (li & 1) else "gbf_a", (M, H), BF16)
@@ -269,12 +269,13 @@ class GptTrunk:
             # ---- attention: hm = hin + c_proj(attn(c_attn(ln1(hin))))
             datt = self._buf("datt", (M, H), BF16)
             hip.gemm(g2_bf, P["wo"].b, M, H, H, hip.NT, out_bf16=datt)
-            hip.gemm(s["att"], g2_bf, H, H, M, hip.TN, lda=H, ldb=H, out_f32=P["wo"].g, accumulate=True)
+            wgrads.append((s["att"], g2_bf, H, H, M, P["wo"].g))
             dqkv = self._buf("dqkv", (M, 3 * H), BF16)
             hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], Bq, S, a.heads, True, dqkv,
                               drop=dsite(li, KIND_ATTN))
             hip.gemm(dqkv, P["wqkv"].b, M, H, 3 * H, hip.NT, out_bf16=dln)
-            hip.gemm(s["ln1"], dqkv, H, 3 * H, M, hip.TN, lda=H, ldb=3 * H, out_f32=P["wqkv"].g, accumulate=True)
+            wgrads.append((s["ln1"], dqkv, H, 3 * H, M, P["wqkv"].g))
+            hip.gemm_wgrad_group(wgrads)   # one launch, whole K per tile: no split-K atomics (gemm256_group_tn_kernel)
             _bias_grad(ws, M, 3 * H, 3 * H, P["bqkv"].g, x_bf16=dqkv)
             g3 = self._buf("g_c" if (li & 1) else "g_d", (M, H), F32)
             g3_bf = self._buf("gbf_c" if (li & 1) else "gbf_d", (M, H), BF16)

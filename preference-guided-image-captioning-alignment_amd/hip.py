@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
 _SIGS = {
     "pgca_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "pgca_gemm_plan": [C.POINTER(GemmArgs)],
+    "pgca_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i32, _vp],
     "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_layernorm_bwd_blocks": [_i32],
@@ -154,6 +155,22 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
         probe.add(e0, e1, 2.0 * M * N * K)
         return
     _check(load().pgca_gemm_bf16(C.byref(a), _stream()), "pgca_gemm_bf16")
+
+
+def gemm_wgrad_group(problems) -> None:
+    """problems: up to four (X [K, M] bf16, dY [K, N] bf16, M, N, K, grad [M, N] f32) tuples -> grad += X^t dY for
+    each, in ONE launch (no split-K atomics).  The four weight gradients of a GPT-2 block."""
+    n = len(problems)
+    arr = (GemmArgs * n)()
+    for a, (X, dY, M, N, K, gout) in zip(arr, problems):
+        a.A, a.B = X.data_ptr(), dY.data_ptr()
+        a.M, a.N, a.K = M, N, K
+        a.lda, a.ldb = M, N
+        a.layout, a.epilogue, a.alpha = TN, EPI_NONE, 1.0
+        a.out_f32, a.ld_out_f32 = gout.data_ptr(), N
+        a.ld_out_bf16 = a.ld_res = a.ld_aux = N
+        a.accumulate = 1
+    _check(load().pgca_gemm_bf16_grouped(arr, n, _stream()), "pgca_gemm_bf16_grouped")
 
 
 def drop_args(seed: int, p: float):

@@ -590,3 +590,21 @@ def test_phase_staggered_gemm_race_screen(hip, layout, shape):
     finally:
         os.environ.pop("PGCA_GEMM_TILE", None)
         os.environ.pop("PGCA_GEMM_RING", None)
+
+
+def test_grouped_weight_gradient_launch(hip):
+    """Four TN problems of different shapes in one grid (no split-K): each equals X^t dY accumulated on the old
+    value; and the fallback (K % 64 != 0) gives the same through ordinary launches."""
+    for K in (2048, 200):
+        shapes = [(512, 256), (256, 256), (256, 768), (256, 512)]
+        probs, refs = [], []
+        for i, (M, N) in enumerate(shapes):
+            x = rnd(K, M, seed=10 + i).bfloat16()
+            dy = rnd(K, N, seed=20 + i).bfloat16()
+            g0 = rnd(M, N, seed=30 + i)
+            gout = g0.clone()
+            probs.append((x, dy, M, N, K, gout))
+            refs.append(g0 + x.float().t() @ dy.float())
+        hip.gemm_wgrad_group(probs)
+        for (x, dy, M, N, K, gout), ref in zip(probs, refs):
+            close(gout, ref, 3e-4, f"grouped wgrad {M}x{N} K={K}")
