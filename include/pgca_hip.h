@@ -251,6 +251,13 @@ int pgca_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64
                float weight_decay, float beta1, float beta2, float eps, float grad_scale, void* stream);
 /* f32 -> bf16 cast of a flat buffer (initial mirror / reference-policy snapshot). */
 int pgca_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+/* hi/lo bf16 split of an f32 matrix along K (NT-Xent similarity at f32-grade accuracy on the bf16 MFMA GEMM,
+ * reference model.py:988-990 computes the similarity in fp32): x f32 [R, P] -> y bf16 [rows_out, 3P],
+ * row r = [hi | hi | lo] (pattern 0, the A operand) or [hi | lo | hi] (pattern 1, the B operand), hi = bf16(x),
+ * lo = bf16(x - hi); rows R..rows_out-1 are zero.  A.B^t over K = 3P then equals x.z up to the dropped lo.lo
+ * term (~2^-17 relative).  P % 8 == 0. */
+int pgca_split_bf16(const float* x, int32_t R, int32_t P, int32_t rows_out, int32_t pattern, void* y_bf16,
+                    void* stream);
 /* y (+)= alpha * x on flat f32 buffers (gradient un-scaling after all-reduce etc.). */
 int pgca_axpy(const float* x, float alpha, float* y, int64_t n, int32_t accumulate, void* stream);
 /* gather / scatter rows of an f32 or bf16 [*, H] matrix by int32 row_map. */

@@ -278,6 +278,36 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict
   }
 }
 
+// x [R, P] f32 -> y [rows_out, 3P] bf16, the hi/lo split of every element laid out along K so that ONE bf16 GEMM
+// with K = 3P and f32 accumulation returns x . z to ~2^-17 relative (hi.hi + hi.lo + lo.hi; the lo.lo term is
+// below f32 rounding of the sum): pattern 0 = [hi | hi | lo] (A side), pattern 1 = [hi | lo | hi] (B side).
+// Rows R..rows_out-1 are zero (K padding of the gradient GEMMs).  One thread per 4 consecutive elements.
+__global__ void split_bf16_kernel(const float* __restrict__ x, int R, int P, int rows_out, int pattern,
+                                  bf16_t* __restrict__ y) {
+  const long long total = (long long)rows_out * (P / 4);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (P / 4)), c = (int)(i % (P / 4)) * 4;
+    bf16x4 hi, lo;
+    if (r < R) {
+      const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * P + c);
+      const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        hi[k] = (bf16_t)f[k];
+        lo[k] = (bf16_t)(f[k] - (float)hi[k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) hi[k] = lo[k] = (bf16_t)0.f;
+    }
+    bf16_t* row = y + (size_t)r * 3 * P + c;
+    *reinterpret_cast<bf16x4*>(row) = hi;
+    *reinterpret_cast<bf16x4*>(row + P) = pattern ? lo : hi;
+    *reinterpret_cast<bf16x4*>(row + 2 * P) = pattern ? hi : lo;
+  }
+}
+
 __global__ void axpy_kernel(const float* __restrict__ x, float alpha, float* __restrict__ y, long long n, int acc) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
@@ -434,6 +464,16 @@ extern "C" int pgca_cast_bf16(const float* x, void* y_bf16, int64_t n, void* str
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for((n + 3) / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x,
                      (bf16_t*)y_bf16, (long long)n);
   return check_launch("pgca_cast_bf16");
+}
+
+extern "C" int pgca_split_bf16(const float* x, int32_t R, int32_t P, int32_t rows_out, int32_t pattern, void* y_bf16,
+                               void* stream) {
+  REQUIRE(x && y_bf16 && R > 0 && P > 0 && (P % 8) == 0 && rows_out >= R && (pattern == 0 || pattern == 1) &&
+              (((uintptr_t)x & 15) == 0),
+          "pgca_split_bf16");
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks_for((long long)rows_out * (P / 4), 256)), dim3(256), 0,
+                     (hipStream_t)stream, x, R, P, rows_out, pattern, (bf16_t*)y_bf16);
+  return check_launch("pgca_split_bf16");
 }
 
 extern "C" int pgca_axpy(const float* x, float alpha, float* y, int64_t n, int32_t accumulate, void* stream) {

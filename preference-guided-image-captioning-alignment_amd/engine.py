@@ -683,7 +683,10 @@ class NTXentEngine:
 
     def __init__(self, ws: Workspace, proj_dim: int, temperature: float, tag: str = "ntx"):
         self.ws, self.P, self.tau, self.tag = ws, proj_dim, float(temperature), tag
+        if proj_dim % 8:
+            raise ValueError("projection_dim must be a multiple of 8 (K alignment of the similarity GEMM)")
         self.saved = None
+        self._tg_off, self._tgN_key, self._consts = None, None, {}
 
     def _buf(self, name, shape, dtype, zero=False):
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
@@ -698,7 +701,7 @@ class NTXentEngine:
         nparts = 2 * ((N + 127) // 128)
         smax, ssum = self._buf(which + ".smax", (B, nparts), F32), self._buf(which + ".ssum", (B, nparts), F32)
         tval, lse = self._buf(which + ".tval", (B,), F32), self._buf(which + ".lse", (B,), F32)
-        hip.gemm(a_bf, b_all_bf, B, N, self.P, hip.NT, epilogue=hip.EPI_ROWSTATS, alpha=1.0 / self.tau,
+        hip.gemm(a_bf, b_all_bf, B, N, 3 * self.P, hip.NT, epilogue=hip.EPI_ROWSTATS, alpha=1.0 / self.tau,
                  targets=targets, stat_max=smax, stat_sum=ssum, stat_ld=nparts, target_val=tval)
         hip.rowstats_combine(smax, ssum, nparts, nparts, tval, B, lse=lse)
         return lse, tval
@@ -706,26 +709,41 @@ class NTXentEngine:
     def forward(self, img_n: torch.Tensor, txt_n: torch.Tensor, img_all: Optional[torch.Tensor] = None,
                 txt_all: Optional[torch.Tensor] = None, offset: int = 0):
         """Normalised local embeddings [B,P] f32 (+ gathered [N,P] when data parallel).
-        Returns (local loss contribution already divided by 2N, lse_r [B], lse_c [B])."""
+        Returns (local loss contribution already divided by 2N, lse_r [B], lse_c [B]).
+
+        The reference evaluates the similarity in fp32 (the loss runs outside autocast, model.py:988-990), and at
+        tau = 0.07 a bf16-rounded cosine is a 3e-2 error on the logit.  The operands therefore go to the MFMA GEMM
+        as hi/lo bf16 pairs concatenated along K (``pgca_split_bf16``): [hi|hi|lo] . [hi|lo|hi] over K = 3P sums
+        hi.hi + hi.lo + lo.hi in f32 - the logits are good to ~1e-5 relative at 3x the (negligible) flops."""
         B, P = img_n.shape
         img_all = img_n if img_all is None else img_all
         txt_all = txt_n if txt_all is None else txt_all
         N = img_all.shape[0]
         bf = {}
         Np = (N + 7) // 8 * 8  # gathered tables are zero-padded to a multiple of 8 rows (K of the dgrad GEMMs)
-        for k, t, rows in (("i", img_n, B), ("t", txt_n, B), ("ia", img_all, Np), ("ta", txt_all, Np)):
-            bf[k] = self._buf("bf." + k, (rows, P), BF16, zero=(rows != t.shape[0]))
-            hip.cast_bf16(t, bf[k], t.numel())
+        for k, t, rows, pattern in (("i", img_n, B, 0), ("t", txt_n, B, 0), ("ia", img_all, Np, 1), ("ta", txt_all, Np, 1)):
+            bf[k] = self._buf("bf3." + k, (rows, 3 * P), BF16)
+            hip.split_bf16(t, t.shape[0], P, rows, pattern, bf[k])
         tg = self.ws.bufs.get(self.tag + ".targets")
-        if tg is None or tg.numel() != B or int(tg[0]) != offset:
+        if tg is None or tg.numel() != B or self._tg_off != offset:
             tg = (torch.arange(B, dtype=I64, device=self.ws.device) + offset).contiguous()
             self.ws.bufs[self.tag + ".targets"] = tg
+            self._tg_off = offset
         lse_r, diag = self._stats(bf["i"], bf["ta"], B, N, tg, "r")
         lse_c, _ = self._stats(bf["t"], bf["ia"], B, N, tg, "c")
         loss = self._buf("loss", (1,), F32)
         hip.ntxent_loss(lse_r, lse_c, diag, B, N, loss)
         self.saved = dict(bf=bf, B=B, N=N, offset=offset, lse_r=lse_r, lse_c=lse_c, tg=tg)
         return loss, lse_r, lse_c
+
+    def _const(self, name: str, n: int, value: float) -> torch.Tensor:
+        """[n] f32 filled with ``value`` (row_scale operand of the DLOGITS epilogue); refilled only when it changes."""
+        key = (n, float(value))
+        t = self._buf(name, (n,), F32)
+        if self._consts.get(name) != key:
+            t.fill_(value)
+            self._consts[name] = key
+        return t
 
     def backward(self, lse_r_all: Optional[torch.Tensor] = None, lse_c_all: Optional[torch.Tensor] = None,
                  loss_scale: float = 1.0):
@@ -738,35 +756,38 @@ class NTXentEngine:
         inv_tau = 1.0 / self.tau
         Np = (N + 7) // 8 * 8
         Bp = (B + 7) // 8 * 8
-        cB = self._buf("cB", (B,), F32)
-        cB.fill_(c)
-        cN = self._buf("cN", (N,), F32)
-        cN.fill_(c)
+        K3 = 3 * P
+        cB = self._const("cB", B, c)
+        cN = self._const("cN", N, c)
         tgN = self.ws.bufs.get(self.tag + ".targetsN")
-        if tgN is None or tgN.numel() != N or s["offset"] != getattr(self, "_tgN_off", None):
+        if tgN is None or tgN.numel() != N or (off, B) != self._tgN_key:
             j = torch.arange(N, dtype=I64, device=self.ws.device) - off
             tgN = torch.where((j >= 0) & (j < B), j, torch.full_like(j, -1)).contiguous()
             self.ws.bufs[self.tag + ".targetsN"] = tgN
-            self._tgN_off = off
+            self._tgN_key = (off, B)
         # G1[i in loc, j in all] = c (p^r_ij - d_ij);  G2[j in loc, i in all] = c (p^c_ij - d_ij)
         g1 = self._buf("g1", (B, Np), BF16)
         g2 = self._buf("g2", (B, Np), BF16)
-        hip.gemm(bf["i"], bf["ta"], B, N, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
+        hip.gemm(bf["i"], bf["ta"], B, N, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
                  row_lse=s["lse_r"], row_scale=cB, out_bf16=g1, ld_out_bf16=Np, out_cols=Np)
-        hip.gemm(bf["t"], bf["ia"], B, N, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
+        hip.gemm(bf["t"], bf["ia"], B, N, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
                  row_lse=s["lse_c"], row_scale=cB, out_bf16=g2, ld_out_bf16=Np, out_cols=Np)
         # G1'[i in all, j in loc] = c (p^r_ij - d_ij);  G2'[j in all, i in loc] = c (p^c_ij - d_ij)
+        # (operand roles swapped: [hi|lo|hi] . [hi|hi|lo] is the same three-term sum)
         g1t = self._buf("g1t", (N, Bp), BF16)
         g2t = self._buf("g2t", (N, Bp), BF16)
-        hip.gemm(bf["ia"], bf["t"], N, B, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
+        hip.gemm(bf["ia"], bf["t"], N, B, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
                  row_lse=lse_r_all, row_scale=cN, out_bf16=g1t, ld_out_bf16=Bp, out_cols=Bp)
-        hip.gemm(bf["ta"], bf["i"], N, B, P, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
+        hip.gemm(bf["ta"], bf["i"], N, B, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
                  row_lse=lse_c_all, row_scale=cN, out_bf16=g2t, ld_out_bf16=Bp, out_cols=Bp)
         dI = self._buf("dI", (B, P), F32)
         dT = self._buf("dT", (B, P), F32)
-        # dI_loc = (1/tau) (G1 T_all + G2'^t T_all);  dT_loc = (1/tau) (G2 I_all + G1'^t I_all)
-        hip.gemm(g1, bf["ta"], B, P, Np, hip.NN, lda=Np, ldb=P, alpha=inv_tau, out_f32=dI)
-        hip.gemm(g2t, bf["ta"], B, P, N, hip.TN, lda=Bp, ldb=P, alpha=inv_tau, out_f32=dI, accumulate=True)
-        hip.gemm(g2, bf["ia"], B, P, Np, hip.NN, lda=Np, ldb=P, alpha=inv_tau, out_f32=dT)
-        hip.gemm(g1t, bf["ia"], B, P, N, hip.TN, lda=Bp, ldb=P, alpha=inv_tau, out_f32=dT, accumulate=True)
+        # dI_loc = (1/tau) (G1 T_all + G2'^t T_all);  dT_loc = (1/tau) (G2 I_all + G1'^t I_all); the gathered
+        # tables enter as hi + lo (columns [0,P) and [P,2P) of the [hi|lo|hi] image, row stride 3P)
+        for part, acc in ((0, False), (1, True)):
+            ta, ia = bf["ta"][:, part * P:], bf["ia"][:, part * P:]
+            hip.gemm(g1, ta, B, P, Np, hip.NN, lda=Np, ldb=K3, alpha=inv_tau, out_f32=dI, accumulate=acc)
+            hip.gemm(g2t, ta, B, P, N, hip.TN, lda=Bp, ldb=K3, alpha=inv_tau, out_f32=dI, accumulate=True)
+            hip.gemm(g2, ia, B, P, Np, hip.NN, lda=Np, ldb=K3, alpha=inv_tau, out_f32=dT, accumulate=acc)
+            hip.gemm(g1t, ia, B, P, N, hip.TN, lda=Bp, ldb=K3, alpha=inv_tau, out_f32=dT, accumulate=True)
         return dI, dT

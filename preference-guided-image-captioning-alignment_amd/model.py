@@ -6,8 +6,9 @@ error behaviour as reference ``models/model.py`` (``PreferenceGuidedCaptioningMo
 :561-619).  Tensors returned are plain device tensors: gradients are produced by the explicit
 backward schedules in ``steps.py`` (``DPOStep`` / ``ContrastiveStep``), not by autograd.
 
-Not implemented (out of the hot path): LoRA adapters, ``generate``.
-Dropout sites run as identity (the reference's eval-mode arithmetic); see DESIGN.md.
+Not implemented (out of the hot path): LoRA adapters.
+``forward`` evaluates the reference's eval-mode arithmetic (no dropout); the training steps in ``steps.py`` apply
+``model.dropout`` at the reference's train-mode sites (fused, counter-based, replayed in the backward - DESIGN.md).
 """
 from __future__ import annotations
 
@@ -216,7 +217,10 @@ class PreferenceGuidedCaptioningModel:
 
     def compute_similarity(self, images, captions, caption_mask) -> torch.Tensor:
         out = self(images=images, caption_ids=captions, caption_mask=caption_mask, mode="contrastive")
-        return out["image_embeddings"] @ out["text_embeddings"].t() / self.temperature
+        from .components import TemperatureScaledSimilarity
+        # reference model.py:947-953: no clamp on the model's own temperature
+        sim = TemperatureScaledSimilarity(self.temperature, min_temp=0.0, max_temp=float("inf"))
+        return sim(out["image_embeddings"], out["text_embeddings"])
 
     def generate_captions(self, *a, **k) -> List[str]:
         raise NotImplementedError("caption generation is outside the training hot path (SURVEY 8f N4)")

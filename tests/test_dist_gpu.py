@@ -91,3 +91,77 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
             assert float((a - b).abs().max()) <= 2e-3 * 1e-3 + 1e-6 or torch.allclose(a, b, atol=2e-4)
         assert abs(st["grad_norm"] - st1["grad_norm"]) <= 2e-3 * st1["grad_norm"] and st["step"] == 1
     assert torch.equal(res[0][3][1], res[1][3][1])                           # replicas stay bit-identical
+
+
+# ----------------------------------------------------------------------------------------------- Stage 1
+def _batch_s1(n, S, vocab, seed):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(4, S + 1, (n,), generator=g)
+    ids = torch.randint(0, vocab, (n, S), generator=g)
+    mask = (torch.arange(S)[None] < lens[:, None]).long()
+    return {"image": torch.randn(n, 3, 64, 64, generator=g), "caption_ids": ids, "caption_mask": mask}
+
+
+def _run_step_s1(batch, dp, tau=0.07):
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.dist import OverlappedTrunkReducer
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    from pgca_amd.steps import ContrastiveStep, FusedOptimizer
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=tiny_arch(), seed=5, device="cuda:0")
+    step = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                           model.text_encoder.engine, temperature=tau, dp=dp, global_negatives=True)
+    segs = [model.store.segments[n] for n in ("vision_head", "text_head", "text_tower")]
+    opt = FusedOptimizer(segs, lr=1e-3, max_grad_norm=1.0, total_steps=10)
+    red = OverlappedTrunkReducer(dp, model.text_encoder.engine.trunk, group=1) if dp else None
+    if red:
+        red.arm()
+    p = ContrastiveStep.prepare(batch, model.device)
+    opt.zero_grad()
+    loss = float(step.loss_and_grads(p["image"], p["ids"], p["mask"]))
+    if red:
+        red.finish(other_segments=segs[:2])
+    world = dp.world if dp else 1
+    grads = [s.grad.clone().cpu() / world for s in segs]
+    opt.step(grad_scale=1.0 / world)
+    torch.cuda.synchronize()
+    return loss, grads, [s.fp32.clone().cpu() for s in segs], opt.state()
+
+
+def _worker_s1(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgca_amd.dist import DataParallel
+        dp = DataParallel(bucket_elems=50000)
+        full = _batch_s1(12, 16, 509, seed=78)
+        lo, hi = dp.shard(12)
+        loss, grads, params, st = _run_step_s1({k: v[lo:hi] for k, v in full.items()}, dp)
+        torch.save((rank, loss, grads, params, st), os.path.join(out_dir, f"s1rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_stage1_global_negatives_equals_single_process(tmp_path):
+    """Stage-1 step with global negatives (all-gather of embeddings + of 2N log-sum-exps, no gradient collective for
+    the loss) on 2 ranks == the single-process step whose local batch IS the concatenated batch
+    (reference model.py:984-1000 on all N rows)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_s1, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    res = [torch.load(tmp_path / f"s1rank{r}.pt", weights_only=False) for r in range(world)]
+    loss1, grads1, params1, st1 = _run_step_s1(_batch_s1(12, 16, 509, seed=78), None)
+    for r in range(world):
+        _, loss, grads, params, st = res[r]
+        assert abs(loss - loss1) <= 2e-4, (loss, loss1)           # every rank reports the GLOBAL loss
+        for a, b in zip(grads, grads1):
+            cosv = float((a.double() @ b.double()) / (a.double().norm() * b.double().norm()))
+            assert cosv >= 0.9999 and abs(float(a.norm()) / float(b.norm()) - 1) <= 2e-3, cosv
+        assert abs(st["grad_norm"] - st1["grad_norm"]) <= 2e-3 * st1["grad_norm"] and st["step"] == 1
+    for a, b in zip(res[0][3], res[1][3]):
+        assert torch.equal(a, b)                                   # replicas stay bit-identical

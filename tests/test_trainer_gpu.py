@@ -22,8 +22,8 @@ def test_loss_classes_match_reference_outputs(golden):
         for tau in (0.07, 0.5):
             k = f"b{b}_t{tau}"
             loss = ContrastiveLoss(temperature=tau)(T(g[k + "_img"]).to(DEV), T(g[k + "_txt"]).to(DEV))
-            # bf16 MFMA operands: |d logit| <= 2^-8 / tau
-            assert abs(float(loss) - float(g[k + "_loss"])) <= (5e-3 if tau == 0.5 else 4e-2), k
+            # hi/lo split bf16 operands (f32-grade logits): well inside the stated 5e-3 at both temperatures
+            assert abs(float(loss) - float(g[k + "_loss"])) <= 2e-4, k
     g = golden("logprob_dpo")
     lw, ll = T(g["logits_w"]).to(DEV), T(g["logits_l"]).to(DEV)
     iw, il, mw, ml = (T(g[k]).to(DEV) for k in ("ids_w", "ids_l", "mask_w", "mask_l"))
