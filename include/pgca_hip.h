@@ -155,7 +155,10 @@ int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, in
 /* ------------------------------------------------------------------ attention (head_dim 64) */
 /* qkv bf16 [B*S, 3*H] (q | k | v, head h at columns h*64), out bf16 [B*S, H], lse f32 [B, heads, S].
  * softmax(q k^t / 8 + mask) v with mask = causal AND key_mask[b, key] != 0 (key_mask int32 [B,S] or NULL).
- * S <= 128.  Replaces SDPA at modeling_gpt2.py:54-72,203-215 and modeling_clip.py:259-277. */
+ * Any S in the forward (one on-chip tile up to 128, key-tiled online softmax beyond); the backward keeps the dQ
+ * accumulators of every 128-query block in registers: S <= PGCA_ATTN_MAX_S.  B <= 65535.
+ * Replaces SDPA at modeling_gpt2.py:54-72,203-215 and modeling_clip.py:259-277. */
+#define PGCA_ATTN_MAX_S 512
 int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int32_t B, int32_t S, int32_t heads,
                        int32_t causal, void* out, float* lse, uint32_t drop_seed, uint32_t drop_threshold,
                        float drop_scale, void* stream);

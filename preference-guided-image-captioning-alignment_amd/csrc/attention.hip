@@ -1,5 +1,6 @@
 // Fused multi-head self-attention for head_dim 64 and S <= 128 (GPT-2 captions: S = 128,
-// CLIP ViT-B/32: T = 50), forward and backward, on MFMA 16x16x32 bf16.
+// CLIP ViT-B/32: T = 50), forward and backward, on MFMA 16x16x32 bf16.  Longer sequences (S = 256 captions,
+// ViT-L/14's 257 tokens) take the key-tiled kernels of attention_tiled.hip through the same two entry points.
 //
 // One workgroup (8 waves, two per SIMD) owns one (batch, head): the whole S x S score tile lives on chip,
 // so nothing is summed across workgroups (no dQ atomics) and the scores never reach HBM.
@@ -9,6 +10,8 @@
 // contraction (V in P.V, and P^t / dS^t / dO / Q / K in the backward products) are read with
 // ds_read_b64_tr_b16, so every tile is staged once in its natural [row][64] layout.
 // Causal blocks above the diagonal are skipped (wave-uniform loop bounds).
+#include <stdlib.h>
+
 #include "common.h"
 
 using namespace pgca;
@@ -376,30 +379,49 @@ constexpr size_t FWD_LDS = 2 * TILE_QKV + TILE_P + SP;
 constexpr size_t BWD_LDS = 4 * TILE_QKV + 2 * TILE_P + 2 * SP * sizeof(float) + SP;
 
 int ensure_lds_attr() {
-  static int done = 0;
-  if (!done) {
-    if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS) !=
-            hipSuccess ||
-        hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) !=
-            hipSuccess) {
-      (void)hipGetLastError();
-      set_error("attention: cannot raise dynamic LDS limit");
-      return PGCA_ERR_LAUNCH;
-    }
-    done = 1;
+  // function-local static: initialised exactly once, thread-safe (C++11)
+  static const bool ok =
+      hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS) ==
+          hipSuccess &&
+      hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) ==
+          hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    set_error("attention: cannot raise dynamic LDS limit");
+    return PGCA_ERR_LAUNCH;
   }
   return PGCA_OK;
 }
 
+// PGCA_ATTN_TILED=1 (read once) routes S <= 128 through the key-tiled kernels too (A/B timing, parity tests)
+bool force_tiled() {
+  static const bool v = [] {
+    const char* e = getenv("PGCA_ATTN_TILED");
+    return e && atoi(e) != 0;
+  }();
+  return v;
+}
+
 }  // namespace
+
+namespace pgca {
+int attention_fwd_tiled(const void* qkv, const int32_t* key_mask, int B, int S, int heads, int causal, void* out,
+                        float* lse, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale, void* stream);
+int attention_bwd_tiled(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_mask,
+                        int B, int S, int heads, int causal, void* dqkv, uint32_t drop_seed, uint32_t drop_threshold,
+                        float drop_scale, void* stream);
+}  // namespace pgca
 
 extern "C" int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int32_t B, int32_t S, int32_t heads,
                                   int32_t causal, void* out, float* lse, uint32_t drop_seed, uint32_t drop_threshold,
                                   float drop_scale, void* stream) {
-  if (!qkv || !out || B <= 0 || S <= 0 || S > SP || heads <= 0) {
-    set_error("pgca_attention_fwd: bad arguments (B=%d S=%d heads=%d; S must be <= %d)", B, S, heads, SP);
+  if (!qkv || !out || B <= 0 || S <= 0 || heads <= 0 || B > 65535) {
+    set_error("pgca_attention_fwd: bad arguments (B=%d S=%d heads=%d)", B, S, heads);
     return PGCA_ERR_INVALID;
   }
+  if (S > SP || force_tiled())
+    return attention_fwd_tiled(qkv, key_mask, B, S, heads, causal, out, lse, drop_seed, drop_threshold, drop_scale,
+                               stream);
   if (ensure_lds_attr()) return PGCA_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3(heads, B), dim3(NT), FWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
                      key_mask, S, heads, causal, (bf16_t*)out, lse, Drop{drop_seed, drop_threshold, drop_scale});
@@ -410,10 +432,13 @@ extern "C" int pgca_attention_bwd(const void* qkv, const void* out, const void* 
                                   const int32_t* key_mask, int32_t B, int32_t S, int32_t heads, int32_t causal,
                                   void* dqkv, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale,
                                   void* stream) {
-  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || S <= 0 || S > SP || heads <= 0) {
-    set_error("pgca_attention_bwd: bad arguments (B=%d S=%d heads=%d; S must be <= %d)", B, S, heads, SP);
+  if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || S <= 0 || S > PGCA_ATTN_MAX_S || heads <= 0 || B > 65535) {
+    set_error("pgca_attention_bwd: bad arguments (B=%d S=%d heads=%d; S must be <= %d)", B, S, heads, PGCA_ATTN_MAX_S);
     return PGCA_ERR_INVALID;
   }
+  if (S > SP || force_tiled())
+    return attention_bwd_tiled(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, drop_seed, drop_threshold,
+                               drop_scale, stream);
   if (ensure_lds_attr()) return PGCA_ERR_LAUNCH;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(heads, B), dim3(NT), BWD_LDS, (hipStream_t)stream, (const bf16_t*)qkv,
                      (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, S, heads, causal, (bf16_t*)dqkv,

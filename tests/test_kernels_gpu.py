@@ -428,8 +428,8 @@ def test_bad_arguments_raise(hip):
     a = torch.zeros(8, 8, dtype=torch.bfloat16, device=dev())
     with pytest.raises(RuntimeError, match="multiple of 8"):
         hip.gemm(a, a, 8, 8, 4, 0, lda=8, ldb=8, out_f32=torch.zeros(8, 8, device=dev()))
-    with pytest.raises(RuntimeError, match="S must be"):
-        hip.attention_fwd(a, None, 1, 200, 1, True, a)
+    with pytest.raises(RuntimeError, match="S must be"):   # the backward keeps dQ of <= 4 query blocks in registers
+        hip.attention_bwd(a, a, a, torch.zeros(8, device=dev()), None, 1, 600, 1, True, a)
 
 
 def test_gemm_split_k_wgrad(hip):
