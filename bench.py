@@ -259,9 +259,14 @@ def main():
         flop_pair = n_fwd * seq_fwd + vit_fwd
         if stage1:  # text tower without LM head, fwd + 2 x bwd, one ViT forward (245.6 GFLOP/pair)
             flop_pair = 3 * (24 * g.hidden ** 2 * g.layers + 4 * S * g.hidden * g.layers) * S + vit_fwd
+        short = {"openai/clip-vit-base-patch32": "CLIP-ViT-B/32", "openai/clip-vit-base-patch16": "CLIP-ViT-B/16",
+                 "openai/clip-vit-large-patch14": "CLIP-ViT-L/14", "gpt2": "GPT-2", "gpt2-medium": "GPT-2-M",
+                 "gpt2-large": "GPT-2-L", "gpt2-xl": "GPT-2-XL"}
+        tag = (f"{short.get(args.vision_model, args.vision_model)}+{short.get(args.text_model, args.text_model)} "
+               f"seq{S}")
         res = {
-            "metric": ("Stage-1 NT-Xent image-caption pairs/sec, CLIP-ViT-B/32+GPT-2-M seq128 (secondary)" if stage1
-                       else "DPO preference-pairs/sec, CLIP-ViT-B/32+GPT-2-M seq128"),
+            "metric": (f"Stage-1 NT-Xent image-caption pairs/sec, {tag} (secondary)" if stage1
+                       else f"DPO preference-pairs/sec, {tag}"),
             "value": pairs / dt, "unit": "pairs/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

@@ -192,9 +192,11 @@ int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t* row_mask, 
                    void* stream);
 int pgca_embed_bwd_blocks(int32_t B, int32_t S);
 
-/* ViT patch gather (modeling_clip.py:200-218): pixels f32 [B,3,I,I] -> bf16 [B*G*G, 3*P*P] in the
- * (c, ky, kx) order of the conv weight, so the bias-free Conv2d is one NT GEMM. */
-int pgca_patchify(const float* pixels, int32_t B, int32_t image, int32_t patch, void* out_bf16, void* stream);
+/* ViT patch gather (modeling_clip.py:200-218): pixels f32 [B,3,I,I] -> bf16 [B*G*G, ld_out] in the
+ * (c, ky, kx) order of the conv weight, so the bias-free Conv2d is one NT GEMM.  ld_out >= 3*P*P; columns
+ * 3*P*P..ld_out-1 are written as zeros (ViT-L/14: 588 -> 640, K of the GEMM padded to its 64-deep tile).  P even. */
+int pgca_patchify(const float* pixels, int32_t B, int32_t image, int32_t patch, int32_t ld_out, void* out_bf16,
+                  void* stream);
 /* x[b, 0] = cls + pos[0]; x[b, 1+p] = patches[b, p] + pos[1+p]  (f32 [B, T, H]). */
 int pgca_vit_assemble(const float* patch_embeds, const float* cls, const float* pos, int32_t B, int32_t T,
                       int32_t H, float* x, void* stream);

@@ -24,6 +24,28 @@ __global__ void patchify_kernel(const float* __restrict__ px, int B, int I, int 
   }
 }
 
+// General patch size (CLIP ViT-L/14: P = 14, D = 588): two consecutive kx per thread (P even), row stride ld >= D,
+// columns D..ld-1 written as zeros (K padding of the patch-embedding GEMM to a multiple of 64).
+__global__ void patchify_pad_kernel(const float* __restrict__ px, int B, int I, int P, int ld,
+                                    bf16_t* __restrict__ out) {
+  const int G = I / P, D = 3 * P * P;
+  const size_t total = (size_t)B * G * G * (ld / 2);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % (ld / 2)) * 2;
+    const size_t row = i / (ld / 2);
+    bf16x2 t;
+    t[0] = t[1] = (bf16_t)0.f;
+    if (col < D) {
+      const int c = col / (P * P), ky = (col / P) % P, kx = col % P;
+      const int b = (int)(row / (G * G)), gy = (int)(row / G) % G, gx = (int)(row % G);
+      const float2 v = *reinterpret_cast<const float2*>(px + (((size_t)b * 3 + c) * I + gy * P + ky) * I + gx * P + kx);
+      t[0] = (bf16_t)v.x;
+      t[1] = (bf16_t)v.y;
+    }
+    *reinterpret_cast<bf16x2*>(out + row * ld + col) = t;
+  }
+}
+
 __global__ void vit_assemble_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                     const float* __restrict__ pos, int B, int T, int H, float* __restrict__ x) {
   const size_t total = (size_t)B * T * H;
@@ -356,12 +378,22 @@ inline int blocks_for(long long work, int per_block, int cap = 4096) {
     return PGCA_ERR_INVALID;                               \
   }
 
-extern "C" int pgca_patchify(const float* pixels, int32_t B, int32_t image, int32_t patch, void* out_bf16,
-                             void* stream) {
-  REQUIRE(pixels && out_bf16 && B > 0 && patch > 0 && image % patch == 0 && patch % 4 == 0, "pgca_patchify");
-  const long long work = (long long)B * 3 * image * image / 4;
-  hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, pixels, B, image,
-                     patch, (bf16_t*)out_bf16);
+extern "C" int pgca_patchify(const float* pixels, int32_t B, int32_t image, int32_t patch, int32_t ld_out,
+                             void* out_bf16, void* stream) {
+  const int D = 3 * patch * patch;
+  REQUIRE(pixels && out_bf16 && B > 0 && patch > 0 && image % patch == 0 && patch % 2 == 0 && image % 2 == 0 &&
+              ld_out >= D && ld_out % 2 == 0 && (((uintptr_t)pixels & 15) == 0),
+          "pgca_patchify");
+  if (patch % 4 == 0 && image % 4 == 0 && ld_out == D) {
+    const long long work = (long long)B * 3 * image * image / 4;
+    hipLaunchKernelGGL(patchify_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, pixels, B,
+                       image, patch, (bf16_t*)out_bf16);
+  } else {
+    const int G = image / patch;
+    const long long work = (long long)B * G * G * (ld_out / 2);
+    hipLaunchKernelGGL(patchify_pad_kernel, dim3(blocks_for(work, 256)), dim3(256), 0, (hipStream_t)stream, pixels, B,
+                       image, patch, ld_out, (bf16_t*)out_bf16);
+  }
   return check_launch("pgca_patchify");
 }
 

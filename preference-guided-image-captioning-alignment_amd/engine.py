@@ -353,7 +353,11 @@ class VisionTower:
         self.seg = seg
         self.cls = seg.w(p + ".embeddings.class_embedding")
         self.pos = seg.w(p + ".embeddings.position_embedding.weight")
-        self.wpatch = seg.wb(p + ".embeddings.patch_embedding.weight")
+        self._wpatch_name = p + ".embeddings.patch_embedding.weight"
+        # K of the patch-embedding GEMM: 3*P*P, padded with zero columns to the GEMM's 64-deep tile when it is not a
+        # multiple of 8 (ViT-L/14: 588 -> 640); the padded bf16 weight is a private copy refreshed when the mirror changes
+        self.patch_k = arch.patch_dim if arch.patch_dim % 8 == 0 else (arch.patch_dim + 63) // 64 * 64
+        self._wpatch_pad, self._wpatch_ver = None, -1
         self.pre = (seg.w(p + ".pre_layrnorm.weight"), seg.w(p + ".pre_layrnorm.bias"))
         self.post = (seg.w(p + ".post_layernorm.weight"), seg.w(p + ".post_layernorm.bias"))
         H = arch.hidden
@@ -372,16 +376,29 @@ class VisionTower:
                 w1=seg.wb(q + ".mlp.fc1.weight"), b1=seg.w(q + ".mlp.fc1.bias"),
                 w2=seg.wb(q + ".mlp.fc2.weight"), b2=seg.w(q + ".mlp.fc2.bias")))
 
+    def _patch_weight(self) -> torch.Tensor:
+        """[H, patch_k] bf16 view of the conv weight (zero-padded copy when 3*P*P is not a multiple of 8)."""
+        w = self.seg.wb(self._wpatch_name).view(self.arch.hidden, self.arch.patch_dim)
+        if self.patch_k == self.arch.patch_dim:
+            return w
+        if self._wpatch_pad is None or self._wpatch_ver != self.seg.bf16_version:
+            if self._wpatch_pad is None:
+                self._wpatch_pad = torch.zeros(self.arch.hidden, self.patch_k, dtype=BF16, device=self.ws.device)
+            self._wpatch_pad[:, :self.arch.patch_dim].copy_(w)
+            self._wpatch_ver = self.seg.bf16_version
+        return self._wpatch_pad
+
     def forward(self, pixels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """pixels [B,3,I,I] f32 -> (features [B,T,H] f32, pooled [B,H] f32, pooled bf16)."""
         a, ws = self.arch, self.ws
         B = pixels.shape[0]
         H, T, G, D = a.hidden, a.tokens, a.grid, a.patch_dim
         M = B * T
-        cols = ws.get("vit.cols", (B * G * G, D), BF16)
-        hip.patchify(pixels, B, a.image, a.patch, cols)
+        Kp = self.patch_k
+        cols = ws.get("vit.cols", (B * G * G, Kp), BF16)
+        hip.patchify(pixels, B, a.image, a.patch, cols, ld_out=Kp)
         pe = ws.get("vit.pe", (B * G * G, H), F32)
-        hip.gemm(cols, self.wpatch, B * G * G, H, D, hip.NT, out_f32=pe)
+        hip.gemm(cols, self._patch_weight(), B * G * G, H, Kp, hip.NT, out_f32=pe)
         x0 = ws.get("vit.x0", (M, H), F32)
         hip.vit_assemble(pe, self.cls, self.pos, B, T, H, x0)
         x = ws.get("vit.x", (M, H), F32)

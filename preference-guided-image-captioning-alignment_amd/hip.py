@@ -62,7 +62,7 @@ _SIGS = {
     "pgca_embed_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
                        _i32, _vp, _vp, _vp],
     "pgca_embed_bwd_blocks": [_i32, _i32],
-    "pgca_patchify": [_vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_patchify": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pgca_vit_assemble": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_seq_reduce": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
     "pgca_logits_logprob": [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
@@ -271,8 +271,9 @@ def embed_bwd(g, ids, row_mask, B, S, H, dwte, dwpe, wte=None, attended=None, ga
                                  _drop_words(drop_e), _stream()), "pgca_embed_bwd")
 
 
-def patchify(pixels, B, image, patch, out_bf16):
-    _check(load().pgca_patchify(_p(pixels), B, image, patch, _p(out_bf16), _stream()), "pgca_patchify")
+def patchify(pixels, B, image, patch, out_bf16, ld_out=None):
+    ld = 3 * patch * patch if ld_out is None else ld_out
+    _check(load().pgca_patchify(_p(pixels), B, image, patch, ld, _p(out_bf16), _stream()), "pgca_patchify")
 
 
 def vit_assemble(patch_embeds, cls, pos, B, T, H, x):

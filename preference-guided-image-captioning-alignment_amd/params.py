@@ -164,6 +164,7 @@ class Segment:
         self.device = device
         self.fp32 = torch.zeros(off, dtype=torch.float32, device=device)
         self.bf16: Optional[torch.Tensor] = None
+        self.bf16_version = 0  # bumped whenever the mirror is refreshed from the masters (derived copies key on it)
         self.grad: Optional[torch.Tensor] = None
         self.exp_avg: Optional[torch.Tensor] = None
         self.exp_avg_sq: Optional[torch.Tensor] = None
@@ -197,6 +198,7 @@ class Segment:
         if self.bf16 is None:
             self.bf16 = torch.empty(self.numel, dtype=torch.bfloat16, device=self.device)
         self.bf16.copy_(self.fp32)
+        self.bf16_version += 1
 
     def ensure_train_state(self) -> None:
         if not self.trainable:
@@ -264,7 +266,7 @@ class ParamStore:
                     raise ValueError(sp.init)
             seg.fp32.copy_(host)
             if seg.bf16 is not None:
-                seg.bf16.copy_(seg.fp32)
+                seg.ensure_bf16()
 
     def state_dict(self, aliases: bool = True) -> "OrderedDict[str, torch.Tensor]":
         """Views (not copies) under the reference's key names.
@@ -300,7 +302,7 @@ class ParamStore:
             raise KeyError(f"missing keys: {missing[:5]} ...")
         for seg in self.segments.values():
             if seg.bf16 is not None:
-                seg.bf16.copy_(seg.fp32)
+                seg.ensure_bf16()
         return missing
 
     def trainable_segments(self) -> List[Segment]:

@@ -322,6 +322,18 @@ def test_patchify_and_assemble(hip):
     assert torch.equal(x, ref)
 
 
+def test_patchify_patch14_pads_k(hip):
+    """CLIP ViT-L/14: 3*14*14 = 588 is not a multiple of 8; the gather pads K to 640 with zero columns."""
+    B, I, P, ld = 2, 224, 14, 640
+    px = rnd(B, 3, I, I, seed=3)
+    G = I // P
+    out = torch.full((B * G * G, ld), 5.0, dtype=torch.bfloat16, device=dev())
+    hip.patchify(px, B, I, P, out, ld_out=ld)
+    ref = px.reshape(B, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(B * G * G, 3 * P * P)
+    assert torch.equal(out[:, :588], ref.bfloat16())
+    assert float(out[:, 588:].abs().max()) == 0.0
+
+
 def test_seq_reduce_dpo_and_row_scale(hip, golden):
     g = golden("logprob_dpo")
     B = 8
