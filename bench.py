@@ -148,6 +148,10 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=16)
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout of the policy (reference: 0.1)")
+    ap.add_argument("--ref-side-stream", action="store_true",
+                    help="run the frozen reference-policy forward on a second HIP stream, concurrently with the policy's")
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="pgca_set_option dispatch knob (e.g. gemm_stagger=8); repeatable")
     ap.add_argument("--stage", type=int, default=2, choices=(1, 2),
                     help="2 (default): the headline Stage-2 DPO step; 1: secondary line, Stage-1 NT-Xent step "
                          "(global negatives over the ranks when N > 1)")
@@ -172,6 +176,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
 
+    for kv in args.set:
+        name, _, val = kv.partition("=")
+        hip.set_option(name, int(val))
     B, S, beta = args.pairs_per_gpu, args.seq_len, 0.1
     log(f"init: world={world} pairs/gpu={B} S={S}")
     arch = make_arch(args.vision_model, args.text_model, 512)
@@ -190,7 +197,7 @@ def main():
         ref = None if args.reference_free else ReferencePolicy(model.store, model.ws)
         step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
                        model.caption_decoder.engine, beta=beta, reference_free=args.reference_free, ref=ref,
-                       dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
+                       ref_side_stream=args.ref_side_stream, dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
         segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
         trunk = model.caption_decoder.engine.trunk
     opt = FusedOptimizer(segs, lr=5e-5 if stage1 else 1e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=500,

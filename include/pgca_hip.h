@@ -36,7 +36,9 @@ typedef enum pgca_status {
   PGCA_ERR_LAUNCH = -2   /* hipLaunch failed; see pgca_last_error() */
 } pgca_status;
 
-int pgca_version(void);
+#define PGCA_ABI_VERSION 200 /* bumped whenever a signature or struct layout below changes */
+int pgca_version(void);        /* == PGCA_ABI_VERSION of the header the library was built from */
+int pgca_sizeof_gemm_args(void); /* sizeof(pgca_gemm_args) as compiled: bindings compare it with their own layout */
 const char* pgca_last_error(void);
 
 /* ------------------------------------------------------------------ GEMM (MFMA bf16) */
@@ -104,9 +106,17 @@ int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
 /* Which kernel pgca_gemm_bf16 would launch for these arguments: schedule*1000000 + tile*100 + K-splits
  * (12801 = general 128^2 register-staged kernel; 256xx = 256^2 LDS-DMA tile with xx K-splits; schedule
  * 0 = 2-stage BK=64 loop (gemm256_kernel, default for the K-strided TN layout), 6 = phase-staggered 4-stage BK=32
- * loop (gemm256s_kernel, default for NT / NN); experimental, selected with PGCA_GEMM_RING: 4 = wide-wave
- * (gemm256w_kernel), 5 = 256x128 two-workgroups-per-CU (gemm_duo_kernel)). */
+ * loop (gemm256s_kernel, default for NT / NN)). */
 int pgca_gemm_plan(const pgca_gemm_args* args);
+/* Process-wide dispatch knobs (tests, micro-benchmarks, tuning).  Defaults come from the environment, read ONCE at
+ * first use - no launch calls getenv:
+ *   "gemm_tile"      0 automatic | 128 | 256                          (PGCA_GEMM_TILE)
+ *   "gemm_schedule"  -1 automatic | 0 | 6 (see pgca_gemm_plan)         (PGCA_GEMM_RING)
+ *   "gemm_group"     1 grouped weight-gradient launch | 0 one by one  (PGCA_GEMM_NO_GROUP=1 -> 0)
+ *   "gemm_stagger"   0..64: start-delay step (x 1024 clocks) of the first wave of workgroups of a many-round
+ *                    gemm256s launch, which de-phases the CUs' epilogue store bursts   (PGCA_GEMM_STAGGER)
+ * Returns PGCA_ERR_INVALID for an unknown name or value. */
+int pgca_set_option(const char* name, int32_t value);
 /* `count` GEMMs in one launch.  Up to four TN problems with epilogue NONE and an f32 (accumulating) output - the four
  * weight gradients of one GPT-2 block (autograd of Conv1D c_attn / c_proj / c_fc / mlp.c_proj, reference
  * modeling_gpt2.py:203,222-224,229-243 under trainer.py:494,606 loss.backward()) - run as ONE grid with the whole K per

@@ -12,6 +12,9 @@
 // (XOR-swizzled, conflict-free for both fragment read kinds), double-buffered: the next
 // tile's global loads are issued before the current tile's MFMAs and written to the other
 // LDS buffer after them (one barrier per K tile).
+#include <atomic>
+#include <string>
+
 #include "gemm_device.h"
 
 namespace {
@@ -293,8 +296,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_group_tn_kernel(const pgca_gro
 constexpr size_t GEMM256_LDS = 4 * TILE2_BYTES;  // 128 KiB
 
 int ensure_gemm256_attr() {
-  static int done = 0;
-  if (!done) {
+  static std::atomic<int> done{0};
+  if (!done.load(std::memory_order_acquire)) {
     hipError_t e1 = hipFuncSetAttribute((const void*)gemm256_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)GEMM256_LDS);
     hipError_t e2 = hipFuncSetAttribute((const void*)gemm256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -308,7 +311,7 @@ int ensure_gemm256_attr() {
       set_error("gemm256: cannot raise dynamic LDS limit");
       return PGCA_ERR_LAUNCH;
     }
-    done = 1;
+    done.store(1, std::memory_order_release);  // idempotent: a racing second caller only repeats the same calls
   }
   return PGCA_OK;
 }
@@ -319,7 +322,7 @@ int ensure_gemm256_attr() {
 int plan_tile(const pgca_gemm_args& a, int* splits_out) {
   const int ncols = a.epilogue == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
   const int ntm2 = (a.M + BM2 - 1) / BM2, ntn2 = (ncols + BN2 - 1) / BN2;
-  const char* force = getenv("PGCA_GEMM_TILE");
+  const int force = gemm_tuning().tile;
   const int nk_total = a.K / BK;
   int splits = 1;
   const bool splittable = a.epilogue == PGCA_EPI_NONE && a.accumulate && a.out_f32 && !a.out_bf16 && !a.bias &&
@@ -330,27 +333,59 @@ int plan_tile(const pgca_gemm_args& a, int* splits_out) {
     if (splits > 16) splits = 16;
     if (splits < 1) splits = 1;
   }
-  const bool want256 = force ? atoi(force) == 256 : (ntm2 * ntn2 * splits >= 192);
+  const bool want256 = force ? force == 256 : (ntm2 * ntn2 * splits >= 192);
   *splits_out = splits;
   return ((a.K % BK) == 0 && want256 && a.M >= 8 && ncols >= 8) ? 256 : 128;
 }
 
 }  // namespace
 
-// Schedule of the 256^2 tile: 0 = gemm256_kernel (8 waves, 2-stage BK=64, the default), 4 = gemm256w_kernel
-// (gemm_wide.hip: 4 waves x 128x128, asm-pipelined 4-stage BK=32 ring; slower today, selectable with
-// PGCA_GEMM_RING=4).  Earlier 8-wave schedules (BK=32 ring, phased halves, phased ring) measured within +-10 % of
-// the default in isolation and equal end to end and were removed; DESIGN.md section 5 has the numbers.
+// Schedule of the 256^2 tile: 0 = gemm256_kernel (2-stage BK=64 loop), 6 = gemm256s_kernel (gemm_phase.hip: phase-staggered
+// wave groups, 4-stage BK=32 ring).  Schedules that did not pay (BK=32 ring with plain barriers, phased halves, a 4-wave
+// 128x128-per-wave asm pipeline, a 256x128 two-workgroups-per-CU tile) were measured, documented in DESIGN.md section 5 and
+// removed from the library.
 static int plan_variant(const pgca_gemm_args& a) {
-  const char* env = getenv("PGCA_GEMM_RING");
-  if (env) {
-    const int v = atoi(env);
-    return (v == 4 || v == 5 || v == 6) ? v : 0;
-  }
-  // K-contiguous A (forward, data gradients, LM head): the phase-staggered loop (gemm_phase.hip) is 3-12 % faster;
-  // the K-strided weight-gradient layout pays two transposed LDS reads per fragment in the load phases and stays
-  // on the plain 2-stage loop.
+  const int forced = gemm_tuning().schedule;
+  if (forced >= 0) return forced == 6 ? 6 : 0;
+  // K-contiguous A (forward, data gradients, LM head): the phase-staggered loop is 3-12 % faster; the K-strided
+  // weight-gradient layout pays two transposed LDS reads per fragment in the load phases and stays on the 2-stage loop.
   return a.layout == PGCA_TN ? 0 : 6;
+}
+
+namespace pgca {
+GemmTuning& gemm_tuning() {
+  static GemmTuning t = [] {
+    auto env = [](const char* name, int dflt) {
+      const char* e = getenv(name);
+      return e ? atoi(e) : dflt;
+    };
+    GemmTuning v;
+    v.tile = env("PGCA_GEMM_TILE", 0);
+    v.schedule = env("PGCA_GEMM_RING", -1);
+    v.group = env("PGCA_GEMM_NO_GROUP", 0) ? 0 : 1;
+    v.stagger = env("PGCA_GEMM_STAGGER", 0);
+    return v;
+  }();
+  return t;
+}
+}  // namespace pgca
+
+extern "C" int pgca_set_option(const char* name, int32_t value) {
+  if (!name) {
+    set_error("pgca_set_option: null name");
+    return PGCA_ERR_INVALID;
+  }
+  GemmTuning& t = gemm_tuning();
+  const std::string n(name);
+  if (n == "gemm_tile" && (value == 0 || value == 128 || value == 256)) t.tile = value;
+  else if (n == "gemm_schedule" && (value == -1 || value == 0 || value == 6)) t.schedule = value;
+  else if (n == "gemm_group" && (value == 0 || value == 1)) t.group = value;
+  else if (n == "gemm_stagger" && value >= 0 && value <= 64) t.stagger = value;
+  else {
+    set_error("pgca_set_option: unknown option or value out of range (%s = %d)", name, value);
+    return PGCA_ERR_INVALID;
+  }
+  return PGCA_OK;
 }
 
 extern "C" int pgca_gemm_plan(const pgca_gemm_args* args) {
@@ -419,14 +454,6 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       dim3 grid2(ntm2 * ntn2, (nk_total + nkps - 1) / nkps), block2(512);
       const int variant = plan_variant(a);
       if (variant == 6) return launch_gemm256s(b, ntm2, ntn2, nkps, (int)grid2.y, stream);
-      if (variant == 5) {
-        const int rc = launch_gemm_duo(b, nkps, (int)grid2.y, stream);
-        if (rc != 1) return rc;
-      }
-      if (variant == 4) {
-        const int rc = launch_gemm256w(b, ntm2, ntn2, nkps, (int)grid2.y, stream);
-        if (rc != 1) return rc;  // 1: epilogue not implemented by the wide-wave kernel, use the 8-wave one
-      }
       switch (a.layout) {
         case PGCA_NT: hipLaunchKernelGGL((gemm256_kernel<0, 0>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
         case PGCA_NN: hipLaunchKernelGGL((gemm256_kernel<0, 1>), grid2, block2, GEMM256_LDS, s, b, ntm2, ntn2, nkps); break;
@@ -452,7 +479,7 @@ extern "C" int pgca_gemm_bf16_grouped(const pgca_gemm_args* args, int32_t count,
     set_error("pgca_gemm_bf16_grouped: no problems");
     return PGCA_ERR_INVALID;
   }
-  bool groupable = count <= 4 && !getenv("PGCA_GEMM_NO_GROUP");
+  bool groupable = count <= 4 && gemm_tuning().group;
   for (int i = 0; i < count && groupable; ++i) {
     const pgca_gemm_args& a = args[i];
     groupable = a.layout == PGCA_TN && a.A && a.B && a.K > 0 && (a.K % BK) == 0 && a.M >= 8 && a.N >= 8 &&

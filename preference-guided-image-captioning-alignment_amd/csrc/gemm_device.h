@@ -1,19 +1,23 @@
-// Device-side building blocks shared by the GEMM translation units (gemm.hip, gemm_wide.hip): operand staging
+// Device-side building blocks shared by the GEMM translation units (gemm.hip, gemm_phase.hip): operand staging
 // geometry, MFMA fragment readers, the fused epilogues and the LDS-DMA issue helpers.  Everything here has
-// internal linkage; the cross-TU symbols are pgca::launch_gemm256w (gemm_wide.hip) and pgca::launch_gemm_duo (gemm_duo.hip).
+// internal linkage; the cross-TU symbols are pgca::launch_gemm256s (gemm_phase.hip) and pgca::gemm_tuning (gemm.hip).
 #pragma once
 #include <stdlib.h>
 
 #include "common.h"
 
 namespace pgca {
-// Wide-wave 256 x 256 kernel (gemm_wide.hip).  Returns 0 when launched, 1 when the epilogue/layout is not
-// one it implements (caller falls back to the 8-wave kernel), < 0 on error.
-int launch_gemm256w(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int nsplit, void* stream);
-// 256 x 128 tile, 4 waves, two workgroups per CU (gemm_duo.hip).  nk_per_split in 64-deep tiles.
-int launch_gemm_duo(const pgca_gemm_args& a, int nk_per_split, int nsplit, void* stream);
 // 256 x 256, 8 waves, phase-staggered wave groups, 4-stage BK=32 ring (gemm_phase.hip).
 int launch_gemm256s(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int nsplit, void* stream);
+
+// Process-wide dispatch knobs (pgca_set_option / environment, read ONCE): nothing on the launch path calls getenv.
+struct GemmTuning {
+  int tile;      // 0 = automatic, 128 / 256 = force that kernel family      (PGCA_GEMM_TILE)
+  int schedule;  // -1 = automatic, 0 = 2-stage BK=64 loop, 6 = phase-staggered (PGCA_GEMM_RING)
+  int group;     // 1 = the four weight gradients of a block in one grid        (PGCA_GEMM_NO_GROUP inverts)
+  int stagger;   // start delay step of the first wave of workgroups, in units of 1024 clocks (PGCA_GEMM_STAGGER)
+};
+GemmTuning& gemm_tuning();
 }  // namespace pgca
 
 using namespace pgca;
@@ -511,20 +515,6 @@ __device__ __forceinline__ void run_epilogue(const pgca_gemm_args& a, f32x4 (&ac
     case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
   }
-}
-
-// Epilogues of the decoder trunk only - what the experimental tile variants (gemm_wide.hip, gemm_duo.hip) implement;
-// everything else falls back to gemm256_kernel.
-__device__ __forceinline__ void run_epilogue_trunk(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int mh,
-                                                   int n0, int wn, int lane, int wave) {
-  switch (a.epilogue) {
-    case PGCA_EPI_GELU_NEW: epilogue_store<PGCA_EPI_GELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    case PGCA_EPI_DGELU_NEW: epilogue_store<PGCA_EPI_DGELU_NEW>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-    default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
-  }
-}
-__device__ __host__ __forceinline__ bool trunk_epilogue(int epi) {
-  return epi == PGCA_EPI_NONE || epi == PGCA_EPI_GELU_NEW || epi == PGCA_EPI_DGELU_NEW;
 }
 
 constexpr int BM2 = 256, BN2 = 256;

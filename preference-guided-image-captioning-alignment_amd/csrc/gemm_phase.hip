@@ -91,8 +91,19 @@ __device__ __forceinline__ void wait_vm_p() {
   } while (0)
 
 template <int LA, int LB>
-__global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split) {
+__global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split,
+                                                          int stagger) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smems[];  // [4 stages][A 16 KiB | B 16 KiB]
+
+  // De-phasing: with 128 KiB of LDS one workgroup owns a CU, every CU starts its tile at the same time and all 256
+  // epilogues hit HBM together (store bursts at the HBM rate while the matrix pipes idle, then the reverse).  The
+  // FIRST wave of workgroups (one per CU) therefore starts in four time slots `stagger` x 1024 clocks apart; later
+  // workgroups inherit their CU's offset, so epilogue traffic of one quarter of the chip overlaps the main loops of
+  // the rest.  Costs 3 x stagger x 1024 clocks once per launch (the tail), so it is used on many-round launches only.
+  if (stagger > 0 && gridDim.y == 1 && blockIdx.x < 256) {
+    const int slot = (blockIdx.x >> 3) & 3;
+    for (int i = 0; i < slot * stagger; ++i) __builtin_amdgcn_s_sleep(16);  // 16 x 64 clocks
+  }
 
   const int nwg = ntm * ntn;
   int bid = blockIdx.x;
@@ -251,17 +262,18 @@ constexpr size_t GEMM256S_LDS = (size_t)2 * PSTAGES * PTILE_BYTES;  // 128 KiB
 
 template <int LA, int LB>
 int launch_s(const pgca_gemm_args& a, int ntm, int ntn, int nkps, int nsplit, hipStream_t s) {
-  static int attr_done = 0;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)gemm256s_kernel<LA, LB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)GEMM256S_LDS) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("gemm256s: cannot raise dynamic LDS limit");
-      return PGCA_ERR_LAUNCH;
-    }
-    attr_done = 1;
+  static const bool attr_ok = hipFuncSetAttribute((const void*)gemm256s_kernel<LA, LB>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)GEMM256S_LDS) == hipSuccess;  // once, thread-safe
+  if (!attr_ok) {
+    (void)hipGetLastError();
+    set_error("gemm256s: cannot raise dynamic LDS limit");
+    return PGCA_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL((gemm256s_kernel<LA, LB>), dim3(ntm * ntn, nsplit), dim3(512), GEMM256S_LDS, s, a, ntm, ntn, nkps);
+  // stagger only where it can pay: >= 3 rounds of workgroups over the 256 CUs
+  const int stagger = (ntm * ntn >= 3 * 256 && nsplit == 1) ? gemm_tuning().stagger : 0;
+  hipLaunchKernelGGL((gemm256s_kernel<LA, LB>), dim3(ntm * ntn, nsplit), dim3(512), GEMM256S_LDS, s, a, ntm, ntn, nkps,
+                     stagger);
   return check_launch("pgca_gemm_bf16(256 phase-staggered)");
 }
 

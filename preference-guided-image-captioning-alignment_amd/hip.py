@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
 _SIGS = {
     "pgca_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "pgca_gemm_plan": [C.POINTER(GemmArgs)],
+    "pgca_set_option": [C.c_char_p, _i32],
     "pgca_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i32, _vp],
     "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
@@ -82,7 +83,8 @@ _SIGS = {
     "pgca_axpy": [_vp, _f32, _vp, _i64, _i32, _vp],
     "pgca_gather_rows_bf16": [_vp, _vp, _i32, _i32, _vp, _vp],
 }
-EXPORTS = ["pgca_version", "pgca_last_error"] + list(_SIGS)
+EXPORTS = ["pgca_version", "pgca_last_error", "pgca_sizeof_gemm_args"] + list(_SIGS)
+ABI_VERSION = 200  # include/pgca_hip.h PGCA_ABI_VERSION
 
 _lib = None
 
@@ -99,6 +101,13 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.pgca_version.restype = C.c_int
     lib.pgca_last_error.restype = C.c_char_p
+    if lib.pgca_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} has ABI version {lib.pgca_version()}, this binding expects {ABI_VERSION}: "
+                           "rebuild it with `python -m pgca_amd.build --force`")
+    lib.pgca_sizeof_gemm_args.restype = C.c_int
+    if lib.pgca_sizeof_gemm_args() != C.sizeof(GemmArgs):
+        raise RuntimeError(f"pgca_gemm_args is {lib.pgca_sizeof_gemm_args()} bytes in {LIB_PATH} but "
+                           f"{C.sizeof(GemmArgs)} in the binding: stale library, rebuild it")
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = sig
@@ -179,6 +188,11 @@ def drop_args(seed: int, p: float):
     if p <= 0.0:
         return None
     return (seed & 0xFFFFFFFF, min(0xFFFFFFFF, int(p * 4294967296.0)), 1.0 / (1.0 - p))
+
+
+def set_option(name: str, value: int) -> None:
+    """Process-wide dispatch knob of the library (include/pgca_hip.h: pgca_set_option)."""
+    _check(load().pgca_set_option(name.encode(), int(value)), "pgca_set_option")
 
 
 gemm_probe = None  # optional object with want(layout, epilogue, M, N, K) / add(ev0, ev1, flops)

@@ -50,16 +50,18 @@ SHAPES = [(128, 128, 64), (256, 384, 1024), (200, 136, 72), (77, 1000, 128), (1,
           (512, 768, 256), (300, 520, 192), (1000, 1000, 64)]
 
 
-@pytest.fixture(params=[128, 256, 260, 261, 262])
-def tile(request):
-    """Force the 128^2 register-staged kernel, the 256^2 LDS-DMA kernel with the 2-stage BK=64 loop (256) or
-    its 4-stage BK=32 ring (257).  The 256^2 kernels need K % 64 == 0."""
-    import os
-    os.environ["PGCA_GEMM_TILE"] = "128" if request.param == 128 else "256"
-    os.environ["PGCA_GEMM_RING"] = {260: "4", 261: "5", 262: "6"}.get(request.param, "0")   # 260: wide-wave (gemm_wide.hip), 261: duo 256x128 (gemm_duo.hip)
+@pytest.fixture(params=[128, 256, 262, 263])
+def tile(request, hip):
+    """Force the 128^2 register-staged kernel, the 256^2 LDS-DMA kernel with the 2-stage BK=64 loop (256), its
+    phase-staggered 4-stage BK=32 loop (262), or the latter with the start stagger of the first workgroups on (263).
+    The 256^2 kernels need K % 64 == 0."""
+    hip.set_option("gemm_tile", 128 if request.param == 128 else 256)
+    hip.set_option("gemm_schedule", 6 if request.param >= 262 else 0)
+    hip.set_option("gemm_stagger", 2 if request.param == 263 else 0)
     yield 256 if request.param > 256 else request.param
-    os.environ.pop("PGCA_GEMM_TILE", None)
-    os.environ.pop("PGCA_GEMM_RING", None)
+    hip.set_option("gemm_tile", 0)
+    hip.set_option("gemm_schedule", -1)
+    hip.set_option("gemm_stagger", 0)
 
 
 @pytest.mark.parametrize("layout", [0, 1, 2])
@@ -588,20 +590,20 @@ def test_phase_staggered_gemm_race_screen(hip, layout, shape):
         Bp = torch.zeros(K, ldn, dtype=torch.bfloat16, device=dev())
         Bp[:, :N] = b
         B, ldb = Bp, ldn
-    os.environ["PGCA_GEMM_TILE"] = "256"
+    hip.set_option("gemm_tile", 256)
     try:
-        os.environ["PGCA_GEMM_RING"] = "0"
+        hip.set_option("gemm_schedule", 0)
         want = torch.zeros(M, N, device=dev())
         hip.gemm(A, B, M, N, K, layout, ldb=ldb, out_f32=want)
         close(want, a.float() @ b.float(), 2e-4, "2-stage kernel")
-        os.environ["PGCA_GEMM_RING"] = "6"
+        hip.set_option("gemm_schedule", 6)
         for it in range(25):
             got = torch.full((M, N), float("nan"), device=dev())
             hip.gemm(A, B, M, N, K, layout, ldb=ldb, out_f32=got)
             assert torch.equal(got, want), f"launch {it}: {(got != want).sum().item()} elements differ"
     finally:
-        os.environ.pop("PGCA_GEMM_TILE", None)
-        os.environ.pop("PGCA_GEMM_RING", None)
+        hip.set_option("gemm_tile", 0)
+        hip.set_option("gemm_schedule", -1)
 
 
 def test_grouped_weight_gradient_launch(hip):
