@@ -20,6 +20,8 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libpgca_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "pgca_hip.h")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# diagnostic builds only (e.g. PGCA_EXTRA_FLAGS="-DPGCA_GEMM_TIMING" for the s_memtime stamps of tools/gemm_bench.py)
+FLAGS += os.environ.get("PGCA_EXTRA_FLAGS", "").split()
 
 
 def hipcc() -> str:

@@ -94,6 +94,10 @@ template <int LA, int LB>
 __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a, int ntm, int ntn, int nk_per_split,
                                                           int stagger) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smems[];  // [4 stages][A 16 KiB | B 16 KiB]
+#ifdef PGCA_GEMM_TIMING
+  unsigned long long ts0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory");
+#endif
 
   // De-phasing: with 128 KiB of LDS one workgroup owns a CU, every CU starts its tile at the same time and all 256
   // epilogues hit HBM together (store bursts at the HBM rate while the matrix pipes idle, then the reverse).  The
@@ -253,7 +257,8 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
   asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts3)::"memory");
   if (a.stat_max && a.epilogue != PGCA_EPI_ROWSTATS && lane == 0) {
     float* o = a.stat_max + ((size_t)blockIdx.x * 8 + wave) * 8;
-    o[0] = 0.f; o[1] = (float)(ts2 - ts1); o[2] = (float)(ts3 - ts2); o[3] = (float)(nk / 2);
+    o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)(ts3 - ts2); o[3] = (float)(nk / 2);
+    o[4] = (float)(ts0 & 0xFFFFFFFull); o[5] = (float)(ts3 & 0xFFFFFFFull);  // wrap at 2^28 clocks
   }
 #endif
 }

@@ -290,16 +290,24 @@ def test_stage1_config_geometry_against_oracle(train_mode, tau):
     """Stage 1 at the real widths (BASELINE configs C1 / C3: ViT-B/32 + GPT-2-M, S = 128, P = 512), 2 layers each:
     masked mean, ProjHead 1024 -> 512, text-tower backward at H = 1024 and the NT-Xent backward, in eval mode and in
     train mode (dropout 0.1 with the oracle replaying the same counter-based masks).  tau = 0.5 is what the trainer
-    runs (configs/default.yaml:21); tau = 0.07 (the constructor default, model.py:958) multiplies every bf16 tower
-    error by 14 in the logits, and with random-init weights the image embeddings of a batch are nearly collinear
-    (the class token dominates), so the vision-head gradient is held to cosine 0.95 there - loss and text-tower
-    gradients keep the stated bar."""
+    runs (configs/default.yaml:21); tau = 0.07 is the constructor default (model.py:958).
+
+    Conditioning: with N(0, 0.02) weights the class token of the frozen ViT is almost the same for every image
+    (its image-dependent part is ~4 % of its norm, the size of the bf16 tower error), and the contrastive gradient of
+    the vision head is exactly the part that survives cancellation of the common component - a comparison of noise.
+    The ViT's value / output projections are therefore scaled x4 (in the model AND, through the shared state_dict, in
+    the oracle) so the tower distinguishes images the way a trained one does; nothing else is touched."""
     from pgca_amd.arch import make_arch, with_layers
     from pgca_amd.engine import DropoutPlan
     from pgca_amd.model import PreferenceGuidedCaptioningModel
     from pgca_amd.steps import ContrastiveStep
     arch = with_layers(make_arch("openai/clip-vit-base-patch32", "gpt2-medium", 512), 2, 2)
     model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=arch, seed=13, device="cuda:0")
+    vit = model.store.segments["vit"]
+    for name in vit.index:
+        if name.endswith(("self_attn.v_proj.weight", "self_attn.out_proj.weight")):
+            vit.w(name).mul_(4.0)
+    vit.ensure_bf16()
     gen = torch.Generator().manual_seed(77)
     B, S = 4, 128
     img = torch.randn(B, 3, 224, 224, generator=gen)
@@ -330,8 +338,7 @@ def test_stage1_config_geometry_against_oracle(train_mode, tau):
                  "text_encoder.projection.3.weight", "text_encoder.projection.4.weight",
                  "vision_encoder.projection.0.weight", "vision_encoder.projection.3.bias"):
         c = cos(model.store.g(name), sd[name].grad)
-        bar = 0.95 if (tau < 0.1 and name.startswith("vision_encoder")) else 0.99
-        assert c >= bar, f"{name}: cosine {c}"
+        assert c >= 0.99, f"{name}: cosine {c}"
     assert float(model.store.segments["decoder"].grad.abs().max()) == 0.0
 
 

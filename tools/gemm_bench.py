@@ -34,17 +34,22 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--ring", type=int, default=-1)
+    ap.add_argument("--rows", type=int, default=16384)
     ap.add_argument("--timing", action="store_true", help="needs gemm_wide.o built with -DPGCA_GEMM_TIMING")
     args = ap.parse_args()
-    if args.tile:
-        os.environ["PGCA_GEMM_TILE"] = str(args.tile)
-    if args.ring >= 0:
-        os.environ["PGCA_GEMM_RING"] = str(args.ring)
     dev = torch.device("cuda:0")
     hip.load()
+    if args.tile:
+        hip.set_option("gemm_tile", args.tile)
+    if args.ring >= 0:
+        hip.set_option("gemm_schedule", args.ring)
     for name, layout, M, N, K, epi in SHAPES:
         if args.only and args.only != name:
             continue
+        if M == 16384:
+            M = args.rows
+        if K == 16384:
+            K = args.rows
         g = torch.Generator(device="cpu").manual_seed(1)
         a_shape = (M, K) if layout != hip.TN else (K, M)
         b_shape = (N, K) if layout == hip.NT else (K, N)
@@ -104,8 +109,21 @@ def main():
                     names = ["L0", "B1+w", "M0", "B2", "L1", "B1'+w", "M1", "B2'"]
                     print("   phase clocks per 32-deep tile  group0: " + " ".join(f"{n} {x:.0f}" for n, x in zip(names, g0)))
                     print("                                  group1: " + " ".join(f"{n} {x:.0f}" for n, x in zip(names, g1)))
-                print(f"   per-workgroup ticks (100 MHz? see DESIGN): prologue {m[0]:.0f} main loop {m[1]:.0f} "
+                print(f"   per-workgroup clocks: prologue {m[0]:.0f} main loop {m[1]:.0f} "
                       f"({m[1] / max(float(m[3]), 1):.0f}/K-tile) epilogue {m[2]:.0f}")
+                w0 = tb.view(-1, 8, 8)[:, 0]          # wave 0 of every workgroup (last launch)
+                st, en = w0[:, 4].double(), w0[:, 5].double()
+                if float(en.max()) > 0:
+                    t0 = float(st.min())
+                    wrap = 2.0 ** 28
+                    st, en = (st - t0) % wrap, (en - t0) % wrap
+                    span = float(en.max())
+                    busy = float((en - st).sum()) / 256.0
+                    import numpy as np
+                    q = np.percentile(st.numpy(), [0, 25, 50, 75, 100])
+                    print(f"   launch span {span:.0f} clocks; sum of workgroup lifetimes / 256 CUs = {busy:.0f} "
+                          f"({100 * busy / span:.0f} % of the span); start-time quartiles {q.round(-2)}; "
+                          f"ideal MFMA clocks {2.0 * M * N * K / (256 * 4 * 512 * 2):.0f}")
         print(f"{name:10s} layout={layout} M={M:6d} N={N:6d} K={K:6d} {epi:8s} {us:9.1f} us  "
               f"{2.0 * M * N * K / us / 1e6:8.1f} TFLOP/s", flush=True)
 
