@@ -54,9 +54,9 @@ SHAPES = [(128, 128, 64), (256, 384, 1024), (200, 136, 72), (77, 1000, 128), (1,
 def tile(request, hip):
     """Force the 128^2 register-staged kernel, the 256^2 LDS-DMA kernel with the 2-stage BK=64 loop (256), its
     phase-staggered 4-stage BK=32 loop (262), or the latter with the start stagger of the first workgroups on (263).
-    The 256^2 kernels need K % 64 == 0."""
+    The LDS-DMA kernels need K % 64 == 0."""
     hip.set_option("gemm_tile", 128 if request.param == 128 else 256)
-    hip.set_option("gemm_schedule", 6 if request.param >= 262 else 0)
+    hip.set_option("gemm_schedule", {262: 6, 263: 6}.get(request.param, 0))
     hip.set_option("gemm_stagger", 2 if request.param == 263 else 0)
     yield 256 if request.param > 256 else request.param
     hip.set_option("gemm_tile", 0)
@@ -596,11 +596,12 @@ def test_phase_staggered_gemm_race_screen(hip, layout, shape):
         want = torch.zeros(M, N, device=dev())
         hip.gemm(A, B, M, N, K, layout, ldb=ldb, out_f32=want)
         close(want, a.float() @ b.float(), 2e-4, "2-stage kernel")
-        hip.set_option("gemm_schedule", 6)
-        for it in range(25):
-            got = torch.full((M, N), float("nan"), device=dev())
-            hip.gemm(A, B, M, N, K, layout, ldb=ldb, out_f32=got)
-            assert torch.equal(got, want), f"launch {it}: {(got != want).sum().item()} elements differ"
+        for sched in (6,):
+            hip.set_option("gemm_schedule", sched)
+            for it in range(25):
+                got = torch.full((M, N), float("nan"), device=dev())
+                hip.gemm(A, B, M, N, K, layout, ldb=ldb, out_f32=got)
+                assert torch.equal(got, want), f"schedule {sched} launch {it}: {(got != want).sum().item()} elements differ"
     finally:
         hip.set_option("gemm_tile", 0)
         hip.set_option("gemm_schedule", -1)
