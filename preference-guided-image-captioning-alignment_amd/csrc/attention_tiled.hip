@@ -1,6 +1,6 @@
-// Key-tiled (flash-style) multi-head self-attention for head_dim 64 and ANY sequence length the models of the
-// hot path use beyond one 128-row tile: GPT-2 captions at S = 256 (configs C4/C5, causal + key padding + replayed
-// probability dropout) and CLIP ViT-L/14 at T = 257 (no mask).  attention.hip keeps the S <= 128 single-tile kernels.
+// Key-tiled (flash-style) multi-head self-attention for head_dim 64 and every sequence length of the hot path:
+// GPT-2 captions at S = 128 (one tile) and S = 256 (configs C4/C5, causal + key padding + replayed probability
+// dropout), CLIP ViT-B/32 at T = 50 and ViT-L/14 at T = 257 (no mask).  Entry points: attention.hip.
 //
 // Forward: one workgroup (8 waves) per (head, batch, 128-query block); wave w owns 16 queries and sweeps the key
 // tiles with an online softmax.  Scores are computed TRANSPOSED (S^t = K Q^t) so a lane holds 4 keys of ONE query per

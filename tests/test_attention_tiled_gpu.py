@@ -1,14 +1,9 @@
 """Key-tiled attention (csrc/attention_tiled.hip) against fp32 PyTorch: the sequence lengths of configs C4/C5
 (GPT-2 captions at S = 256: causal + right padding + replayed probability dropout; ViT-L/14 at T = 257: no mask),
-ragged lengths around the 128-row block edges, and the S <= 128 range forced through the tiled kernels."""
-import os
-import subprocess
-import sys
-
+and ragged lengths around the 128-row block edges (S <= 128 is covered by tests/test_kernels_gpu.py)."""
 import pytest
 import torch
 
-from pgca_amd import REPO_ROOT
 from test_kernels_gpu import attn_ref, close, dev, drop_mult, hip, rnd  # noqa: F401  (hip is a fixture)
 
 pytestmark = pytest.mark.gpu
@@ -90,11 +85,3 @@ def test_tiled_attention_is_reproducible(hip):
         res.append((out.clone(), lse.clone(), dqkv.clone()))
     for a, b in zip(*res):
         assert torch.equal(a, b)
-
-
-def test_short_sequences_through_the_tiled_kernels():
-    """PGCA_ATTN_TILED=1 routes S <= 128 through the tiled kernels: the single-tile tests must still pass."""
-    env = dict(os.environ, PGCA_ATTN_TILED="1", PYTHONPATH=REPO_ROOT)
-    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REPO_ROOT, "tests", "test_kernels_gpu.py"), "-x",
-                        "-q", "-m", "gpu", "-k", "attention"], capture_output=True, text=True, env=env, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
