@@ -224,8 +224,9 @@ int pgca_logits_logprob(const float* logits, int32_t ld, int32_t V, const int32_
                         int32_t R, float* out, void* stream);
 /* DPO / preference loss over B pairs (components.py:210-231, model.py:1047-1048).
  * pol_w/pol_l/ref_w/ref_l f32 [B] (ref_* may be NULL = reference-free).
- * loss[0] = mean loss; dpol_w/dpol_l [B] = dLoss/dpol (f32); metrics[4] = reward_margin,
- * reward_accuracy, mean pol_w, mean pol_l (components.py:234-247), all on device (no host sync). */
+ * loss[0] = mean loss; dpol_w/dpol_l [B] = dLoss/dpol (f32), all zero when the loss is not finite (the reference skips
+ * such a batch, trainer.py:606-613); metrics[4] = reward_margin, reward_accuracy, mean pol_w, mean pol_l
+ * (components.py:234-247), all on device (no host sync). */
 int pgca_dpo_loss(const float* pol_w, const float* pol_l, const float* ref_w, const float* ref_l, int32_t B,
                   float beta, float label_smoothing, float* loss, float* dpol_w, float* dpol_l, float* metrics,
                   void* stream);
@@ -256,10 +257,17 @@ int pgca_sqnorm(const float* g, int64_t n, float* part, void* stream);
  *   total_norm, finite flag, clip = min(1, max_norm/(norm+1e-6)) (clip_grad_norm_, trainer.py:511-515,619-623),
  * and - if finite - advances ctrl.step and evaluates the cosine warm-up lr (trainer.py:285-289).
  * ctrl layout (f32[8]): [0] total_norm [1] finite(1/0) [2] clip [3] lr [4] bias_corr1 [5] bias_corr2
- *                       [6] opt_step (as float) [7] sched_step (as float). */
+ *                       [6] opt_step (as float) [7] sched_step (as float).
+ * gate (device, optional): loss of the micro-batch that closes the accumulation group; non-finite -> the step is
+ * skipped like a non-finite norm (the reference drops the group there, trainer.py:481-489 under accumulate()). */
 int pgca_step_control(const float* part, int32_t nparts, float max_norm, float base_lr, int32_t warmup,
                       int32_t total_steps, int32_t sched_stride, float beta1, float beta2, float grad_scale,
-                      float* ctrl, void* stream);
+                      const float* gate, float* ctrl, void* stream);
+/* The reference's per-micro-batch clip_grad_norm_ (trainer.py:511-515,619-623) on a partially accumulated gradient,
+ * without a host sync: coef[0] = min(1, max_norm / (norm + 1e-6)) and coef[1] = norm from the pgca_sqnorm partials of
+ * all segments; pgca_scale_dev multiplies a flat buffer by coef[0]. */
+int pgca_clip_coef(const float* part, int32_t nparts, float max_norm, float* coef, void* stream);
+int pgca_scale_dev(float* x, int64_t n, const float* coef, void* stream);
 /* AdamW (trainer.py:275-281: decoupled decay on every parameter) over a flat segment, gradient scaled by
  * ctrl.clip * grad_scale, skipped entirely when ctrl.finite == 0; refreshes the bf16 mirror. */
 int pgca_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* ctrl,

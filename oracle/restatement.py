@@ -69,16 +69,20 @@ def dropout_multiplier(seed: int, p: float, numel: int) -> torch.Tensor:
 class Dropper:
     """mult(tower, layer, kind, shape) -> multiplier tensor (or None when p == 0)."""
 
-    def __init__(self, base_seed: int, p: float, step: int = 0):
+    def __init__(self, base_seed: int, p: float, step: int = 0, p_gpt: Optional[float] = None):
+        # p: model.dropout at the reference's own sites (model.py:139,341,524,531); p_gpt: HF GPT-2's internal
+        # embd / attn / resid dropouts (GPT2Config default 0.1, never overridden by the reference); None = same as p
         self.base_seed, self.p, self.step = base_seed, p, step
+        self.p_gpt = p if p_gpt is None else p_gpt
 
     def mult(self, tower: int, layer: int, kind: int, shape) -> Optional[torch.Tensor]:
-        if self.p <= 0.0:
+        p = self.p_gpt if kind in (KIND_EMBD, KIND_ATTN, KIND_RESID_ATTN, KIND_RESID_MLP) else self.p
+        if p <= 0.0:
             return None
         n = 1
         for d in shape:
             n *= int(d)
-        return dropout_multiplier(site_seed(self.base_seed, self.step, tower, layer, kind), self.p, n).view(*shape)
+        return dropout_multiplier(site_seed(self.base_seed, self.step, tower, layer, kind), p, n).view(*shape)
 
 
 def _apply(x: torch.Tensor, m: Optional[torch.Tensor]) -> torch.Tensor:

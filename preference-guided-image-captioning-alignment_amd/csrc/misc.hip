@@ -86,23 +86,22 @@ __device__ __forceinline__ float log_sigmoid(float z) {  // stable: min(z,0) - l
 }
 __device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + __expf(-z)); }
 
-// single block; B pairs
+// single block; B pairs.  A non-finite batch loss (a caption with <= 1 real token makes its length-mean 0/0, reference
+// model.py:1082-1083) zeroes the gradient seeds: the micro-batch then contributes nothing, which is what the reference's
+// "skip this batch" (trainer.py:481-489,606-613: no backward) amounts to - decided on the device, no host sync.
 __global__ void dpo_loss_kernel(const float* __restrict__ pw, const float* __restrict__ pl,
                                 const float* __restrict__ rw, const float* __restrict__ rl, int B, float beta,
                                 float ls, float* __restrict__ loss, float* __restrict__ dpw, float* __restrict__ dpl,
                                 float* __restrict__ metrics) {
   __shared__ float red[5][4];
+  __shared__ float s_loss;
   float a_loss = 0.f, a_margin = 0.f, a_acc = 0.f, a_w = 0.f, a_l = 0.f;
+  const float tgt = 1.f - ls;  // label smoothing (components.py:223-228): BCE with target (1 - ls); ls == 0 -> -logsigmoid(z)
   for (int i = threadIdx.x; i < B; i += blockDim.x) {
     const float pol = pw[i] - pl[i];
     const float ref = rw ? rw[i] - rl[i] : 0.f;
     const float z = beta * (pol - ref);
-    // label smoothing (components.py:223-228): BCE with target (1 - ls); ls == 0 -> -logsigmoid(z)
-    const float tgt = 1.f - ls;
     a_loss += -(tgt * log_sigmoid(z) + (1.f - tgt) * log_sigmoid(-z));
-    const float dz = -(tgt * (1.f - sigmoidf(z)) - (1.f - tgt) * sigmoidf(z)) / (float)B;
-    if (dpw) dpw[i] = beta * dz;
-    if (dpl) dpl[i] = -beta * dz;
     a_margin += pol - ref;
     a_acc += pol > ref ? 1.f : 0.f;
     a_w += pw[i];
@@ -118,10 +117,24 @@ __global__ void dpo_loss_kernel(const float* __restrict__ pw, const float* __res
   __syncthreads();
   if (threadIdx.x < 5) {
     const float s = (red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]) / (float)B;
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
       loss[0] = s;
-    else if (metrics)
+      s_loss = s;
+    } else if (metrics) {
       metrics[threadIdx.x - 1] = s;
+    }
+  }
+  __syncthreads();
+  if (dpw || dpl) {
+    const bool live = isfinite(s_loss);
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+      const float pol = pw[i] - pl[i];
+      const float ref = rw ? rw[i] - rl[i] : 0.f;
+      const float z = beta * (pol - ref);
+      const float dz = live ? -(tgt * (1.f - sigmoidf(z)) - (1.f - tgt) * sigmoidf(z)) / (float)B : 0.f;
+      if (dpw) dpw[i] = live ? beta * dz : 0.f;
+      if (dpl) dpl[i] = live ? -beta * dz : 0.f;
+    }
   }
 }
 
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g
 
 __global__ void step_control_kernel(const float* __restrict__ part, int nparts, float max_norm, float base_lr,
                                     int warmup, int total_steps, int sched_stride, float beta1, float beta2,
-                                    float grad_scale, float* __restrict__ ctrl) {
+                                    float grad_scale, const float* __restrict__ gate, float* __restrict__ ctrl) {
   __shared__ double red[4];
   double s = 0.0;
   for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += (double)part[i];
@@ -223,7 +236,10 @@ __global__ void step_control_kernel(const float* __restrict__ part, int nparts, 
   if (threadIdx.x == 0) {
     const double tot = (red[0] + red[1] + red[2] + red[3]) * (double)grad_scale * (double)grad_scale;
     const float norm = (float)sqrt(tot);
-    const bool finite = isfinite(norm);
+    // `gate` (optional): the loss of the micro-batch that closes the accumulation group.  The reference drops the whole
+    // group without stepping when THAT loss is non-finite (its zero_grad() is only real on the boundary micro-step,
+    // trainer.py:481-489 under accelerate's accumulate()).
+    const bool finite = isfinite(norm) && (!gate || isfinite(gate[0]));
     ctrl[0] = norm;
     ctrl[1] = finite ? 1.f : 0.f;
     ctrl[2] = (max_norm > 0.f) ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
@@ -247,6 +263,33 @@ __global__ void step_control_kernel(const float* __restrict__ part, int nparts, 
       ctrl[6] = step;
       ctrl[7] = sched + (float)sched_stride;
     }
+  }
+}
+
+// clip_grad_norm_ on a partially accumulated gradient (the reference clips after EVERY micro-batch, trainer.py:511-515,
+// 619-623): coef[0] = min(1, max_norm / (norm + 1e-6)), norm from the sqnorm partials; then scale_dev multiplies.
+__global__ void clip_coef_kernel(const float* __restrict__ part, int nparts, float max_norm, float* __restrict__ coef) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) s += (double)part[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+    coef[0] = isfinite(norm) ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;  // NaN gradients are left for the step's check
+    coef[1] = norm;
+  }
+}
+__global__ __launch_bounds__(256) void scale_dev_kernel(float* __restrict__ x, long long n, const float* __restrict__ coef) {
+  const float c = coef[0];
+  if (c == 1.f) return;
+  const long long stride = (long long)gridDim.x * blockDim.x * 4;
+  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; e < n; e += stride) {
+    float4 v = *reinterpret_cast<float4*>(x + e);
+    v.x *= c; v.y *= c; v.z *= c; v.w *= c;
+    *reinterpret_cast<float4*>(x + e) = v;
   }
 }
 
@@ -476,11 +519,24 @@ extern "C" int pgca_sqnorm(const float* g, int64_t n, float* part, void* stream)
 
 extern "C" int pgca_step_control(const float* part, int32_t nparts, float max_norm, float base_lr, int32_t warmup,
                                  int32_t total_steps, int32_t sched_stride, float beta1, float beta2, float grad_scale,
-                                 float* ctrl, void* stream) {
+                                 const float* gate, float* ctrl, void* stream) {
   REQUIRE(part && ctrl && nparts > 0, "pgca_step_control");
   hipLaunchKernelGGL(step_control_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nparts, max_norm, base_lr,
-                     warmup, total_steps, sched_stride, beta1, beta2, grad_scale, ctrl);
+                     warmup, total_steps, sched_stride, beta1, beta2, grad_scale, gate, ctrl);
   return check_launch("pgca_step_control");
+}
+
+extern "C" int pgca_clip_coef(const float* part, int32_t nparts, float max_norm, float* coef, void* stream) {
+  REQUIRE(part && coef && nparts > 0 && max_norm > 0.f, "pgca_clip_coef");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nparts, max_norm, coef);
+  return check_launch("pgca_clip_coef");
+}
+
+extern "C" int pgca_scale_dev(float* x, int64_t n, const float* coef, void* stream) {
+  REQUIRE(x && coef && n > 0 && (n % 4) == 0 && (((uintptr_t)x & 15) == 0), "pgca_scale_dev");
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(blocks_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x,
+                     (long long)n, coef);
+  return check_launch("pgca_scale_dev");
 }
 
 extern "C" int pgca_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* ctrl,

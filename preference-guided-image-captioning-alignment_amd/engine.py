@@ -70,23 +70,38 @@ class DropoutPlan:
     embd/attn/resid dropouts, modeling_gpt2.py:66,224,242,604).  Masks are a pure function of
     (base seed, step, tower, layer, site kind, element index), so every backward kernel replays the forward's
     mask from the same triple instead of reading a stored one.  ``site`` returns the ``(seed, threshold,
-    scale)`` triple the kernels take, or None when dropout is off (p == 0 or eval)."""
+    scale)`` triple the kernels take, or None when dropout is off (p == 0 or eval).
 
-    def __init__(self, p: float = 0.0, base_seed: int = 0):
+    Two probabilities, as in the reference: ``p`` (``model.dropout``, configs/default.yaml:22) at the reference's own
+    sites - projection heads, ``vision_projection``, cross-attention weights - and ``p_gpt`` at GPT-2's internal
+    embd / attn / resid sites, which HF fixes at 0.1 in ``GPT2Config`` whatever ``model.dropout`` says (the reference
+    never overrides them, model.py:311-312,505-506).  ``p_gpt=None`` means "same as p" (kernel tests, the bench)."""
+
+    GPT_KINDS = (KIND_EMBD, KIND_ATTN, KIND_RESID_ATTN, KIND_RESID_MLP)
+
+    def __init__(self, p: float = 0.0, base_seed: int = 0, p_gpt: Optional[float] = None):
         self.p, self.base_seed, self.step, self.active = float(p), int(base_seed), 0, True
+        self.p_gpt = float(p) if p_gpt is None else float(p_gpt)
+
+    def _p(self, kind: int) -> float:
+        return self.p_gpt if kind in self.GPT_KINDS else self.p
 
     def _site(self, step: int, tower: int, layer: int, kind: int):
         seed = _hash32(_hash32(self.base_seed * 0x9E3779B1 + step) ^ ((tower << 24) | ((layer & 0xFFFF) << 8) | kind))
-        return hip.drop_args(seed, self.p)
+        return hip.drop_args(seed, self._p(kind))
+
+    @property
+    def on(self) -> bool:
+        return self.active and (self.p > 0.0 or self.p_gpt > 0.0)
 
     def site(self, tower: int, layer: int, kind: int):
-        if not self.active or self.p <= 0.0:
+        if not self.on:
             return None
         return self._site(self.step, tower, layer, kind)
 
     def bind(self, tower: int):
         """Closure over the CURRENT step: the backward of this forward replays exactly these seeds."""
-        if not self.active or self.p <= 0.0:
+        if not self.on:
             return None
         step = self.step
         return lambda layer, kind: self._site(step, tower, layer, kind)

@@ -76,7 +76,9 @@ _SIGS = {
     "pgca_ntxent_loss": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "pgca_sqnorm_blocks": [_i64],
     "pgca_sqnorm": [_vp, _i64, _vp, _vp],
-    "pgca_step_control": [_vp, _i32, _f32, _f32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp],
+    "pgca_step_control": [_vp, _i32, _f32, _f32, _i32, _i32, _i32, _f32, _f32, _f32, _vp, _vp, _vp],
+    "pgca_clip_coef": [_vp, _i32, _f32, _vp, _vp],
+    "pgca_scale_dev": [_vp, _i64, _vp, _vp],
     "pgca_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _vp],
     "pgca_cast_bf16": [_vp, _vp, _i64, _vp],
     "pgca_split_bf16": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
@@ -347,9 +349,18 @@ def sqnorm(g, n, part):
     _check(load().pgca_sqnorm(_p(g), n, _p(part), _stream()), "pgca_sqnorm")
 
 
-def step_control(part, nparts, max_norm, base_lr, warmup, total_steps, sched_stride, beta1, beta2, grad_scale, ctrl):
+def step_control(part, nparts, max_norm, base_lr, warmup, total_steps, sched_stride, beta1, beta2, grad_scale, ctrl,
+                 gate=None):
     _check(load().pgca_step_control(_p(part), nparts, max_norm, base_lr, warmup, total_steps, sched_stride, beta1,
-                                    beta2, grad_scale, _p(ctrl), _stream()), "pgca_step_control")
+                                    beta2, grad_scale, _p(gate), _p(ctrl), _stream()), "pgca_step_control")
+
+
+def clip_coef(part, nparts, max_norm, coef):
+    _check(load().pgca_clip_coef(_p(part), nparts, max_norm, _p(coef), _stream()), "pgca_clip_coef")
+
+
+def scale_dev(x, n, coef):
+    _check(load().pgca_scale_dev(_p(x), n, _p(coef), _stream()), "pgca_scale_dev")
 
 
 def adamw(p, g, m, v, p_bf16, n, ctrl, weight_decay, beta1, beta2, eps, grad_scale=1.0):

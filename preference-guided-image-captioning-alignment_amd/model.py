@@ -174,7 +174,10 @@ class PreferenceGuidedCaptioningModel:
     def state_dict(self):
         return self.store.state_dict(aliases=True)
 
-    def load_state_dict(self, sd, strict: bool = False):
+    def load_state_dict(self, sd, strict: bool = True):
+        """Strict like ``nn.Module.load_state_dict``: every parameter of this model must be present with its shape
+        (the reference's duplicate registrations - ``clip_model.*``, ``lm_head.weight`` - and its unused CLIP text
+        tower are accepted and ignored)."""
         return self.store.load_state_dict(sd, strict=strict)
 
     def sync_bf16(self) -> None:

@@ -46,18 +46,34 @@ class FusedOptimizer:
         self.ctrl = torch.zeros(8, dtype=F32, device=dev)
         self.nblocks = [hip.sqnorm_blocks(s.numel) for s in self.segments]
         self.part = torch.zeros(sum(self.nblocks), dtype=F32, device=dev)
+        self.coef = torch.ones(2, dtype=F32, device=dev)   # [clip factor, norm] of clip_partial()
 
     def zero_grad(self) -> None:
         for s in self.segments:
             s.grad.zero_()
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def _sqnorms(self) -> None:
         off = 0
         for s, nb in zip(self.segments, self.nblocks):
             hip.sqnorm(s.grad, s.numel, self.part[off:off + nb])
             off += nb
+
+    def clip_partial(self) -> None:
+        """The reference's ``clip_grad_norm_`` on a PARTIALLY accumulated (local) gradient - it clips after every
+        micro-batch (trainer.py:511-515,619-623).  Norm, factor and scaling stay on the device."""
+        if self.max_norm <= 0:
+            return
+        self._sqnorms()
+        hip.clip_coef(self.part, self.part.numel(), self.max_norm, self.coef)
+        for s in self.segments:
+            hip.scale_dev(s.grad, s.numel, self.coef)
+
+    def step(self, grad_scale: float = 1.0, gate: Optional[torch.Tensor] = None) -> None:
+        """``gate``: 1-element device tensor (the loss of the micro-batch closing the accumulation group); a
+        non-finite value skips the step on the device, as the reference drops that group (pgca_step_control)."""
+        self._sqnorms()
         hip.step_control(self.part, self.part.numel(), self.max_norm, self.lr, self.warmup, self.total, self.stride,
-                         self.betas[0], self.betas[1], grad_scale, self.ctrl)
+                         self.betas[0], self.betas[1], grad_scale, self.ctrl, gate=gate)
         for s in self.segments:
             hip.adamw(s.fp32, s.grad, s.exp_avg, s.exp_avg_sq, s.bf16, s.numel, self.ctrl, self.wd, self.betas[0],
                       self.betas[1], self.eps, grad_scale)

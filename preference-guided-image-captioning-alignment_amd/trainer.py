@@ -10,13 +10,20 @@ semantics:
 * AdamW(lr, wd=0.01, betas=(0.9, 0.999), eps=1e-8) on every parameter that receives gradients,
   cosine schedule with warm-up, total steps = len(loader) // accum * epochs, scheduler advanced
   ``world`` times per optimiser step (accelerate/scheduler.py:54-82);
-* non-finite loss / gradients skip the update (trainer.py:481-508, 606-613) - decided ON THE DEVICE
-  from the all-reduced global norm, so every rank takes the same decision without a host sync;
+* a micro-batch whose loss is not finite contributes no gradient (the reference skips its backward,
+  trainer.py:481-489, 606-613); when it is the micro-batch that CLOSES an accumulation group the whole group is
+  dropped without an optimiser / scheduler step (the reference's ``zero_grad()`` is only real there); non-finite
+  gradients skip the step (trainer.py:494-508).  All of it is decided ON THE DEVICE (gradient seeds zeroed by
+  ``pgca_dpo_loss``, ``gate`` + all-reduced norm in ``pgca_step_control``): every rank takes the same decision and the
+  step loop never reads a loss back;
 * ``global_step`` counts micro-batches (trainer.py:525, 633).
 
 Differences (documented in DESIGN.md): no ``.item()`` per micro-batch (losses are read from the device every
-``logging_steps``), validation loss is averaged across ranks, gradients are clipped once per optimiser step
-unless ``mi355x.clip_every_micro_step`` asks for the reference's per-micro-step clipping.
+``logging_steps``), so ``global_step`` also counts the skipped micro-batches; validation loss is averaged across
+ranks; early stopping is decided identically on every rank; gradients are clipped once per optimiser step unless
+``mi355x.clip_every_micro_step`` asks for the reference's per-micro-step clipping; ``load_checkpoint`` also restores
+the optimiser / scheduler / dropout-stream state the reference forgets (trainer.py:836-853) and resumes after the
+saved epoch.
 """
 from __future__ import annotations
 
@@ -51,6 +58,7 @@ class PreferenceGuidedTrainer:
         self.beta = float(config.get("training.stage2.dpo_beta", 0.1))
         self.current_stage, self.global_step, self.epoch = 1, 0, 0
         self.best_val_loss, self.patience_counter = float("inf"), 0
+        self._resume: Optional[Dict[str, Any]] = None   # optimiser / scheduler / dropout state of a loaded checkpoint
         self.output_dir = Path(config.get("paths.output_dir", "./outputs"))
         self.checkpoint_dir = self.output_dir / "checkpoints"
         if self.is_main_process:
@@ -62,19 +70,43 @@ class PreferenceGuidedTrainer:
         return self.dp.rank == 0
 
     def _dropout_plan(self, stage: int) -> DropoutPlan:
-        """model.dropout (configs/default.yaml:22) at the reference's train-mode sites; per-rank, per-stage seed."""
+        """model.dropout (configs/default.yaml:22) at the reference's own train-mode sites and HF GPT-2's fixed 0.1 at
+        its internal embd / attn / resid sites (``mi355x.gpt2_pdrop``); per-rank, per-stage seed."""
         seed = int(self.config.get("training.seed", 42)) * 1000 + stage * 100 + self.dp.rank
-        return DropoutPlan(float(getattr(self.model, "dropout", 0.0) or 0.0), base_seed=seed)
+        plan = DropoutPlan(float(getattr(self.model, "dropout", 0.0) or 0.0), base_seed=seed,
+                           p_gpt=float(self.config.get("mi355x.gpt2_pdrop", 0.1)))
+        if self._resume is not None and self._resume.get("stage") == stage:
+            plan.step = int(self._resume.get("dropout_step", 0))
+        self._plan = plan
+        return plan
+
+    def _check_loader(self, loader, what: str) -> None:
+        """Every rank must see the same number of batches: the loop's collectives are per batch."""
+        n = len(loader)
+        lo = self.dp.all_reduce_max_scalar(-float(n), self.device)
+        hi = self.dp.all_reduce_max_scalar(float(n), self.device)
+        if -lo != hi:
+            raise RuntimeError(f"{what}: ranks hold between {int(-lo)} and {int(hi)} batches; shard the dataset evenly "
+                               "(scripts/train.py truncates to a multiple of the world size)")
 
     # ------------------------------------------------------------------ optimiser
     def _setup_optimizer(self, stage: int, num_training_steps: int) -> FusedOptimizer:
         sc = self.config.get(f"training.stage{stage}")
         names = ("vision_head", "text_tower", "text_head") if stage == 1 else ("vision_head", "decoder")
+        if stage == 1 and not self.model.store.segments["text_tower"].trainable:
+            raise NotImplementedError("Stage 1 with freeze_text_backbone=True is not supported on the MI355X path: the "
+                                      "text tower's backward always produces its weight gradients")
         segs = [self.model.store.segments[n] for n in names if self.model.store.segments[n].trainable]
-        return FusedOptimizer(segs, lr=sc["learning_rate"], weight_decay=sc.get("weight_decay", 0.01),
-                              betas=(0.9, 0.999), eps=1e-8, max_grad_norm=sc.get("max_grad_norm"),
-                              warmup_steps=sc.get("warmup_steps", 0), total_steps=num_training_steps,
-                              sched_stride=self.dp.world)
+        opt = FusedOptimizer(segs, lr=sc["learning_rate"], weight_decay=sc.get("weight_decay", 0.01),
+                             betas=(0.9, 0.999), eps=1e-8, max_grad_norm=sc.get("max_grad_norm"),
+                             warmup_steps=sc.get("warmup_steps", 0), total_steps=num_training_steps,
+                             sched_stride=self.dp.world)
+        if self._resume is not None and self._resume.get("stage") == stage and self._resume.get("optimizer"):
+            opt.load_state_dict({k: ([t.to(self.device) for t in v] if isinstance(v, list) else v.to(self.device))
+                                 for k, v in self._resume["optimizer"].items()})
+            self.logger.info(f"Restored optimiser / scheduler state of stage {stage} "
+                             f"(step {opt.state()['step']}, schedule position {opt.state()['sched_step']})")
+        return opt
 
     # ------------------------------------------------------------------ epoch loops
     def _run_epoch(self, loader, opt: FusedOptimizer, micro_step, reducer: Optional[OverlappedTrunkReducer],
@@ -95,14 +127,17 @@ class PreferenceGuidedTrainer:
             loss_sum += torch.nan_to_num(loss, nan=0.0, posinf=0.0, neginf=0.0) * ok
             finite_cnt += ok
             self.global_step += 1
-            if clip_micro and not boundary and opt.max_norm > 0:
-                self._clip_partial(opt)
+            if clip_micro and not boundary:
+                opt.clip_partial()
             if boundary:
                 if reducer is not None:
                     reducer.finish(other_segments=extra_segments)
                 else:
                     self.dp.all_reduce_grads(opt.segments)
-                opt.step(grad_scale=1.0 / self.dp.world)
+                # a non-finite loss on the closing micro-batch drops the group (pgca_step_control gate); under data
+                # parallelism the gate must be the same on every rank: a NaN anywhere makes the summed value NaN
+                gate = loss if self.dp.world == 1 else self.dp.all_reduce_sum(loss.clone())
+                opt.step(grad_scale=1.0 / self.dp.world, gate=gate)
                 opt.zero_grad()
             if self.global_step % log_every == 0 and self.is_main_process:
                 st = opt.state()
@@ -113,15 +148,6 @@ class PreferenceGuidedTrainer:
         if skipped:
             self.logger.warning(f"Epoch had {skipped} NaN batches out of {n_batches} total")
         return float(loss_sum) / n if n > 0 else 0.0
-
-    def _clip_partial(self, opt: FusedOptimizer) -> None:
-        """Reference quirk: ``clip_grad_norm_`` runs on every micro-step (trainer.py:511-515,619-623), i.e. on
-        the partially accumulated gradient."""
-        norm = math.sqrt(sum(float((s.grad.double() ** 2).sum()) for s in opt.segments))
-        c = min(1.0, opt.max_norm / (norm + 1e-6))
-        if c < 1.0:
-            for s in opt.segments:
-                s.grad.mul_(c)
 
     @torch.no_grad()
     def _validate(self, loader, loss_only) -> float:
@@ -194,7 +220,13 @@ class PreferenceGuidedTrainer:
 
     def _train_loop(self, stage, sc, opt, train_loader, val_loader, micro, val, reducer, extra):
         metrics: Dict[str, List[float]] = {"train_loss": [], "val_loss": [], "learning_rates": []}
-        for epoch in range(sc["num_epochs"]):
+        self._check_loader(train_loader, f"stage {stage} training loader")
+        self._check_loader(val_loader, f"stage {stage} validation loader")
+        first = 0
+        if self._resume is not None and self._resume.get("stage") == stage:
+            first = int(self._resume.get("epoch", -1)) + 1   # the reference restarts at epoch 0 (trainer.py:848)
+            self._resume = None
+        for epoch in range(first, sc["num_epochs"]):
             self.epoch = epoch
             t0 = time.time()
             train_loss = self._run_epoch(train_loader, opt, micro, reducer, extra, sc, stage)
@@ -205,9 +237,15 @@ class PreferenceGuidedTrainer:
             metrics["learning_rates"].append(lr)
             self._log_metrics({"epoch": epoch, "stage": stage, "train_loss": train_loss, "val_loss": val_loss,
                                "learning_rate": lr, "epoch_seconds": time.time() - t0})
+            # every rank runs the same bookkeeping on the same (rank-reduced) val_loss, so all of them leave the loop
+            # together; only the file writes are rank 0's (the reference updates best_val_loss inside the rank-0-only
+            # save and hangs the other ranks in the next collective)
             should_stop = self._check_early_stopping(val_loss, sc)
+            improved = val_loss < self.best_val_loss
             if self.is_main_process:
-                self._save_checkpoint(epoch, opt, val_loss, stage)
+                self._save_checkpoint(epoch, opt, val_loss, stage, improved)
+            if improved:
+                self.best_val_loss = val_loss
             if should_stop:
                 self.logger.info(f"Early stopping triggered at epoch {epoch}")
                 break
@@ -235,24 +273,36 @@ class PreferenceGuidedTrainer:
         self.patience_counter += 1
         return self.patience_counter >= patience
 
-    def _save_checkpoint(self, epoch: int, opt: FusedOptimizer, val_loss: float, stage: int) -> None:
+    def _save_checkpoint(self, epoch: int, opt: FusedOptimizer, val_loss: float, stage: int, improved: bool) -> None:
         """Same dict layout and file names as reference trainer.py:770-813 (key names of ``model_state_dict``
-        are the reference's, including the duplicated ViT and the tied lm_head)."""
+        are the reference's, including the duplicated ViT and the tied lm_head).  ``mi355x_state`` is extra: what a
+        bit-faithful resume needs beyond the reference's keys (the reference's consumers ignore unknown keys)."""
         ck = {"epoch": epoch, "stage": stage, "global_step": self.global_step,
               "model_state_dict": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
               "optimizer_state_dict": {k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu())
                                        for k, v in opt.state_dict().items()},
               "scheduler_state_dict": {"sched_step": opt.state()["sched_step"]},
-              "val_loss": val_loss, "config": self.config.config}
+              "val_loss": val_loss, "config": self.config.config,
+              "mi355x_state": {"dropout_step": int(getattr(self, "_plan", DropoutPlan()).step),
+                               "best_val_loss": min(self.best_val_loss, val_loss),
+                               "patience_counter": self.patience_counter}}
         torch.save(ck, self.checkpoint_dir / f"checkpoint_stage{stage}_epoch{epoch}.pt")
-        if val_loss < self.best_val_loss:
-            self.best_val_loss = val_loss
+        if improved:
             torch.save(ck, self.checkpoint_dir / f"best_model_stage{stage}.pt")
 
     def load_checkpoint(self, path: str) -> None:
+        """Reference trainer.py:836-853 (model + epoch / global_step / stage / best_val_loss) plus what it forgets:
+        the AdamW moments, the step and schedule counters and the dropout stream position are restored when the next
+        ``train_stage{stage}`` builds its optimiser, and that stage continues after the saved epoch.  Loading is
+        strict, as ``nn.Module.load_state_dict`` is: a checkpoint of another architecture raises."""
         ck = torch.load(path, map_location="cpu", weights_only=False)
-        self.model.load_state_dict(ck["model_state_dict"])
+        self.model.load_state_dict(ck["model_state_dict"], strict=True)
         self.model.sync_bf16()
         self.epoch, self.current_stage = ck.get("epoch", 0), ck.get("stage", 1)
         self.global_step = ck.get("global_step", 0)
+        extra = ck.get("mi355x_state", {})
+        self.best_val_loss = float(extra.get("best_val_loss", ck.get("val_loss", float("inf"))))
+        self.patience_counter = int(extra.get("patience_counter", 0))
+        self._resume = {"stage": self.current_stage, "epoch": self.epoch, "optimizer": ck.get("optimizer_state_dict"),
+                        "dropout_step": extra.get("dropout_step", 0)}
         self.logger.info(f"Loaded checkpoint from {path}")

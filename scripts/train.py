@@ -55,8 +55,10 @@ def set_random_seeds(seed: int) -> None:
 
 
 def shard(ds, dp):
-    idx = list(range(dp.rank, len(ds), dp.world))
-    return torch.utils.data.Subset(ds, idx)
+    """Rank r takes items r, r + world, ... of the first len // world * world items: every rank holds the same
+    number of samples, hence the same number of batches (the step loop's collectives are per batch)."""
+    n = len(ds) // dp.world * dp.world
+    return torch.utils.data.Subset(ds, list(range(dp.rank, n, dp.world)))
 
 
 def main():

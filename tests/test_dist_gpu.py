@@ -165,3 +165,49 @@ def test_two_rank_stage1_global_negatives_equals_single_process(tmp_path):
         assert abs(st["grad_norm"] - st1["grad_norm"]) <= 2e-3 * st1["grad_norm"] and st["step"] == 1
     for a, b in zip(res[0][3], res[1][3]):
         assert torch.equal(a, b)                                   # replicas stay bit-identical
+
+
+# ----------------------------------------------------------------------------------------------- early stopping
+def _worker_es(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgca_amd import REPO_ROOT
+        from pgca_amd.arch import tiny_arch
+        from pgca_amd.config import Config
+        from pgca_amd.model import PreferenceGuidedCaptioningModel
+        from pgca_amd.trainer import PreferenceGuidedTrainer
+        cfg = Config(os.path.join(REPO_ROOT, "configs", "default.yaml"))
+        cfg.set("paths.output_dir", os.path.join(out_dir, f"out{rank}"))
+        cfg.set("training.stage2.num_epochs", 6)
+        cfg.set("training.stage2.learning_rate", 0.0)            # nothing improves: val loss is constant
+        cfg.set("training.stage2.early_stopping_patience", 2)
+        cfg.set("training.stage2.gradient_accumulation_steps", 1)
+        cfg.set("training.stage1.gradient_accumulation_steps", 1)
+        model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=tiny_arch(), dropout=0.0, seed=5,
+                                                device="cuda:0")
+        mk = lambda seed: [_batch(2, 16, 509, seed=seed + 10 * rank + i) for i in range(2)]  # noqa: E731
+        tr = PreferenceGuidedTrainer(model, cfg, [], [], mk(1), mk(50))
+        out = tr.train_stage2()
+        torch.save((rank, len(out["train_loss"]), out["val_loss"], tr.best_val_loss), os.path.join(out_dir, f"es{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_leave_the_loop_together_on_early_stopping(tmp_path):
+    """The reference updates best_val_loss inside the rank-0-only checkpoint save, so only rank 0 ever reaches its
+    patience and the others block in the next all-reduce.  Here every rank tracks it on the rank-reduced val loss:
+    with a constant val loss and patience 2 both ranks stop after epoch 2 (epoch 0 sets the best)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_es, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0, "a rank hung or failed"
+    res = [torch.load(tmp_path / f"es{r}.pt", weights_only=False) for r in range(world)]
+    assert res[0][1] == res[1][1] == 3                             # epochs run: 0 (best), 1, 2 -> stop
+    assert res[0][2] == res[1][2]                                  # identical (rank-reduced) validation losses
+    assert res[0][3] == res[1][3] == res[0][2][0]
