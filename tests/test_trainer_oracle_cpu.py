@@ -58,4 +58,5 @@ def test_matches_torch_adamw_with_per_micro_batch_clipping():
             opt.zero_grad()
     assert torch.allclose(sd["w"].detach(), w.detach(), atol=1e-7) and torch.allclose(sd["b"].detach(), b.detach(), atol=1e-7)
     _, o2 = _run(None, False)                    # one clip per optimiser step: different first moments (AdamW's update is
-    assert not torch.allclose(o2["exp_avg"]["w"], o["exp_avg"]["w"], rtol=1e-3)   # scale-free, so compare m, not w)
+    differs = any(not torch.allclose(o2["exp_avg"][k], o["exp_avg"][k], rtol=1e-4) for k in ("w", "b"))   # scale-free,
+    assert differs                                # so compare the moments, not the weights
