@@ -230,6 +230,14 @@ int pgca_logits_logprob(const float* logits, int32_t ld, int32_t V, const int32_
 int pgca_dpo_loss(const float* pol_w, const float* pol_l, const float* ref_w, const float* ref_l, int32_t B,
                   float beta, float label_smoothing, float* loss, float* dpol_w, float* dpol_l, float* metrics,
                   void* stream);
+/* The index work of the log-prob gather on the device (reference model.py:1069-1083, components.py:340-357: shift,
+ * mask product, gather index), replacing the host pass of a collate function: for ids / mask int64 [Bq, S] keeps the
+ * rows (b, t) with mask[b, t+1] != 0, sorted by sequence: row_map[r] = b*S + t, targets[r] = ids[b, t+1] (bit-exact),
+ * seq_of_row[r] = b (each of capacity Bq*(S-1)); counts[b] = kept rows of sequence b; n_rows[0] = total;
+ * mask32 (optional) = int32 0/1 copy of the mask (key mask of pgca_attention_*). */
+int pgca_seq_batch_prepare(const int64_t* ids, const int64_t* mask, int32_t Bq, int32_t S, int32_t* counts,
+                           int32_t* mask32, int32_t* row_map, int64_t* targets, int32_t* seq_of_row, int32_t* n_rows,
+                           void* stream);
 /* row_scale[r] = dseq[seq_of_row[r]] * (mode ? 1/count : 1): dLoss/d tok_lp per compact row. */
 int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,
                    int32_t mode, float* row_scale, void* stream);

@@ -19,6 +19,7 @@ MI355X_DEFAULTS = {
     "allreduce_bucket_elems": 64 * 1024 * 1024,
     "allreduce_layer_group": 4,
     "clip_every_micro_step": False,                             # reference quirk
+    "prefetch_depth": 2,                                        # batches prepared ahead on a side stream (0 = inline)
     "gpt2_pdrop": 0.1,                                          # HF GPT2Config embd/attn/resid dropout (train mode)
     "allreduce_bf16": False,                                    # bf16-compressed gradient all-reduce (halves xGMI bytes)
 }

@@ -138,6 +138,53 @@ __global__ void dpo_loss_kernel(const float* __restrict__ pw, const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------ batch index preparation
+// The integer work of the loss (reference model.py:1069-1083 / components.py:340-357: shift, mask product, gather index)
+// on the device, so a batch needs no host pass: rows (b, t) with mask[b, t+1] != 0 are kept, sorted by sequence;
+// row_map[r] = b*S + t (the hidden-state row whose logits score the token), targets[r] = ids[b, t+1] (bit-exact int64),
+// seq_of_row[r] = b, counts[b] = number of kept rows of sequence b, n_rows[0] = their total.
+// One wave per sequence; mask32 (optional output) is the int32 0/1 key mask the attention kernels take.
+__global__ void seq_counts_kernel(const long long* __restrict__ mask, int Bq, int S, int* __restrict__ counts,
+                                  int* __restrict__ mask32) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= Bq) return;
+  int c = 0;
+  for (int t = lane; t < S; t += 64) {
+    const int m = mask[(size_t)b * S + t] != 0;
+    if (mask32) mask32[(size_t)b * S + t] = m;
+    if (t >= 1) c += m;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if (lane == 0) counts[b] = c;
+}
+__global__ void seq_compact_kernel(const long long* __restrict__ ids, const long long* __restrict__ mask,
+                                   const int* __restrict__ counts, int Bq, int S, int* __restrict__ row_map,
+                                   long long* __restrict__ targets, int* __restrict__ seq_of_row,
+                                   int* __restrict__ n_rows) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= Bq) return;
+  int off = 0;  // exclusive prefix of the counts: Bq <= a few hundred, every wave sums its own
+  for (int i = lane; i < b; i += 64) off += counts[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) off += __shfl_xor(off, o);
+  if (b == Bq - 1 && lane == 0) n_rows[0] = off + counts[b];
+  for (int t0 = 0; t0 < S - 1; t0 += 64) {
+    const int t = t0 + lane;
+    const bool keep = t < S - 1 && mask[(size_t)b * S + t + 1] != 0;
+    const unsigned long long bal = __ballot(keep);
+    if (keep) {
+      const int r = off + __popcll(bal & ((1ull << lane) - 1ull));
+      row_map[r] = b * S + t;
+      targets[r] = ids[(size_t)b * S + t + 1];
+      seq_of_row[r] = b;
+    }
+    off += __popcll(bal);
+  }
+}
+
 // ------------------------------------------------------------------------------------ pooling / normalise
 __global__ void masked_mean_fwd_kernel(const float* __restrict__ f, const int* __restrict__ mask, int S, int H,
                                        float* __restrict__ pooled) {
@@ -454,6 +501,17 @@ extern "C" int pgca_seq_reduce(const float* tok_lp, const int32_t* seq_of_row, i
   hipLaunchKernelGGL(seq_reduce_kernel, dim3((nseq + 3) / 4), dim3(256), 0, (hipStream_t)stream, tok_lp, seq_of_row,
                      nrows, nseq, seq_count, mode, seq_lp);
   return check_launch("pgca_seq_reduce");
+}
+
+extern "C" int pgca_seq_batch_prepare(const int64_t* ids, const int64_t* mask, int32_t Bq, int32_t S, int32_t* counts,
+                                      int32_t* mask32, int32_t* row_map, int64_t* targets, int32_t* seq_of_row,
+                                      int32_t* n_rows, void* stream) {
+  REQUIRE(ids && mask && counts && row_map && targets && seq_of_row && n_rows && Bq > 0 && S > 1, "pgca_seq_batch_prepare");
+  hipLaunchKernelGGL(seq_counts_kernel, dim3((Bq + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)mask, Bq, S, counts, mask32);
+  hipLaunchKernelGGL(seq_compact_kernel, dim3((Bq + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const long long*)ids,
+                     (const long long*)mask, counts, Bq, S, row_map, (long long*)targets, seq_of_row, n_rows);
+  return check_launch("pgca_seq_batch_prepare");
 }
 
 extern "C" int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,

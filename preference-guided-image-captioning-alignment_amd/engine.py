@@ -128,23 +128,52 @@ class SeqBatch:
     S: int
 
 
-def make_seq_batch(ids: torch.Tensor, mask: torch.Tensor, device) -> SeqBatch:
-    """Host-side (collate-time) index preparation; ``ids``/``mask`` may be CPU or device tensors."""
-    ids_c = ids.detach().to("cpu", I64)
-    mask_c = mask.detach().to("cpu")
-    Bq, S = ids_c.shape
-    keep = mask_c[:, 1:] != 0
-    if not bool(keep.any()):
-        raise ValueError("no scored token in the batch (every caption has <= 1 real token)")
-    b_idx, t_idx = torch.nonzero(keep, as_tuple=True)            # row-major: sorted by sequence
-    row_map = (b_idx * S + t_idx).to(I32)
-    targets = ids_c[:, 1:][keep].contiguous()
-    counts = keep.sum(dim=1).to(I32)
-    n = int(row_map.numel())
+class PendingSeqBatch:
+    """Index preparation issued on the current stream; ``result()`` waits for the one number the host needs (how many
+    rows are scored - it sizes the LM-head launch) and hands out the views."""
+
+    def __init__(self, ids, mask32, row_map, targets, seq_of_row, counts, n_host, event, Bq, S):
+        self._f = (ids, mask32, row_map, targets, seq_of_row, counts)
+        self._n, self._ev, self.Bq, self.S = n_host, event, Bq, S
+
+    def result(self) -> "SeqBatch":
+        self._ev.synchronize()
+        n = int(self._n[0])
+        if n <= 0:
+            raise ValueError("no scored token in the batch (every caption has <= 1 real token)")
+        ids, mask32, row_map, targets, seq_of_row, counts = self._f
+        return SeqBatch(ids=ids, mask=mask32, row_map=row_map[:n], targets=targets[:n], seq_of_row=seq_of_row[:n],
+                        counts=counts, n_rows=n, Bq=self.Bq, S=self.S)
+
+
+def prepare_seq_batch_async(ids: torch.Tensor, mask: torch.Tensor, device) -> PendingSeqBatch:
+    """``ids`` / ``mask`` [Bq, S] on the host (pinned: the copy is asynchronous) or on the device.  Everything -
+    the int32 key mask, the shifted gather indices, the compaction, the per-sequence counts - runs on the current HIP
+    stream (``pgca_seq_batch_prepare``); nothing is computed on the host."""
     dev = torch.device(device)
-    return SeqBatch(ids=ids_c.to(dev), mask=(mask_c != 0).to(I32).to(dev), row_map=row_map.to(dev),
-                    targets=targets.to(dev), seq_of_row=b_idx.to(I32).to(dev), counts=counts.to(dev),
-                    n_rows=n, Bq=Bq, S=S)
+    ids_d = ids.detach().to(dev, I64, non_blocking=True).contiguous()
+    mask_d = mask.detach().to(dev, I64, non_blocking=True).contiguous()
+    Bq, S = ids_d.shape
+    if S < 2:
+        raise ValueError("sequences need at least 2 positions (the first token is never scored)")
+    cap = Bq * (S - 1)
+    mask32 = torch.empty(Bq, S, dtype=I32, device=dev)
+    counts = torch.empty(Bq, dtype=I32, device=dev)
+    row_map = torch.empty(cap, dtype=I32, device=dev)
+    targets = torch.empty(cap, dtype=I64, device=dev)
+    seq_of_row = torch.empty(cap, dtype=I32, device=dev)
+    n_dev = torch.empty(1, dtype=I32, device=dev)
+    hip.seq_batch_prepare(ids_d, mask_d, Bq, S, counts, mask32, row_map, targets, seq_of_row, n_dev)
+    n_host = torch.empty(1, dtype=I32, pin_memory=True)
+    n_host.copy_(n_dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingSeqBatch(ids_d, mask32, row_map, targets, seq_of_row, counts, n_host, ev, Bq, S)
+
+
+def make_seq_batch(ids: torch.Tensor, mask: torch.Tensor, device) -> SeqBatch:
+    """Token batch + index work of the loss, prepared on the device (one host wait: the scored-row count)."""
+    return prepare_seq_batch_async(ids, mask, device).result()
 
 
 # ------------------------------------------------------------------------------------------ helpers

@@ -69,6 +69,7 @@ _SIGS = {
     "pgca_logits_logprob": [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
     "pgca_dpo_loss": [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_row_scale": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
+    "pgca_seq_batch_prepare": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pgca_masked_mean_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_masked_mean_bwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_l2norm_fwd": [_vp, _i32, _i32, _vp, _vp, _vp],
@@ -311,6 +312,12 @@ def logits_logprob(logits, ld, V, row_map, targets, R, out):
 def dpo_loss(pol_w, pol_l, ref_w, ref_l, B, beta, label_smoothing, loss, dpol_w=None, dpol_l=None, metrics=None):
     _check(load().pgca_dpo_loss(_p(pol_w), _p(pol_l), _p(ref_w), _p(ref_l), B, beta, label_smoothing, _p(loss),
                                 _p(dpol_w), _p(dpol_l), _p(metrics), _stream()), "pgca_dpo_loss")
+
+
+def seq_batch_prepare(ids, mask, Bq, S, counts, mask32, row_map, targets, seq_of_row, n_rows, stream=None):
+    _check(load().pgca_seq_batch_prepare(_p(ids), _p(mask), Bq, S, _p(counts), _p(mask32), _p(row_map), _p(targets),
+                                         _p(seq_of_row), _p(n_rows), _stream() if stream is None else stream),
+           "pgca_seq_batch_prepare")
 
 
 def row_scale(dseq, seq_of_row, seq_count, nrows, mode, out):

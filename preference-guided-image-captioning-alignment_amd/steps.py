@@ -141,7 +141,10 @@ class DPOStep:
         chosen and rejected are stacked along the sequence-batch dimension."""
         ids = torch.cat([batch["preferred_ids"], batch["rejected_ids"]], dim=0)
         mask = torch.cat([batch["preferred_mask"], batch["rejected_mask"]], dim=0)
-        return {"image": batch["image"].to(device, F32, non_blocking=True), "seq": make_seq_batch(ids, mask, device)}
+        if not ids.is_cuda and batch["preferred_ids"].is_pinned():   # keep the H2D copies asynchronous
+            ids, mask = ids.pin_memory(), mask.pin_memory()
+        image = batch["image"].to(device, F32, non_blocking=True)
+        return {"image": image, "seq": make_seq_batch(ids, mask, device)}
 
     def forward(self, images: torch.Tensor, sb: SeqBatch, save: bool = True):
         B = images.shape[0]

@@ -37,6 +37,7 @@ import torch
 
 from .dist import DataParallel, OverlappedTrunkReducer
 from .engine import DropoutPlan
+from .input import BatchPrefetcher
 from .model import PreferenceGuidedCaptioningModel
 from .steps import ContrastiveStep, DPOStep, FusedOptimizer, ReferencePolicy
 
@@ -109,7 +110,15 @@ class PreferenceGuidedTrainer:
         return opt
 
     # ------------------------------------------------------------------ epoch loops
-    def _run_epoch(self, loader, opt: FusedOptimizer, micro_step, reducer: Optional[OverlappedTrunkReducer],
+    def _feed(self, loader, prepare):
+        """Prepared batches: pinned staging + H2D + device-side index preparation ``mi355x.prefetch_depth`` batches
+        ahead on a side stream (input.BatchPrefetcher); depth 0 prepares inline."""
+        depth = int(self.config.get("mi355x.prefetch_depth", 2))
+        if depth > 0 and self.device.type == "cuda":
+            return BatchPrefetcher(loader, prepare, self.device, depth)
+        return (prepare(b, self.device) for b in loader)
+
+    def _run_epoch(self, loader, opt: FusedOptimizer, prepare, micro_step, reducer: Optional[OverlappedTrunkReducer],
                    extra_segments, stage_cfg: Dict[str, Any], stage: int) -> float:
         self.model.train()
         n_batches = len(loader)
@@ -118,7 +127,7 @@ class PreferenceGuidedTrainer:
         loss_sum = torch.zeros(1, dtype=torch.float32, device=self.device)
         finite_cnt = torch.zeros(1, dtype=torch.float32, device=self.device)
         opt.zero_grad()
-        for step, batch in enumerate(loader):
+        for step, batch in enumerate(self._feed(loader, prepare)):
             boundary = ((step + 1) % self.accum == 0) or (step + 1 == n_batches)
             if reducer is not None:
                 reducer.arm() if boundary else reducer.disarm()
@@ -150,10 +159,10 @@ class PreferenceGuidedTrainer:
         return float(loss_sum) / n if n > 0 else 0.0
 
     @torch.no_grad()
-    def _validate(self, loader, loss_only) -> float:
+    def _validate(self, loader, prepare, loss_only) -> float:
         self.model.eval()
         tot = torch.zeros(2, dtype=torch.float32, device=self.device)
-        for batch in loader:
+        for batch in self._feed(loader, prepare):
             loss = loss_only(batch)
             if bool(torch.isfinite(loss)):
                 tot[0] += loss.reshape(())
@@ -177,15 +186,14 @@ class PreferenceGuidedTrainer:
                                          group=int(self.config.get("mi355x.allreduce_layer_group", 4)))
         extra = [s for s in opt.segments if s is not reducer.seg]
 
-        def micro(batch, scale):
-            p = ContrastiveStep.prepare(batch, self.device)
+        def micro(p, scale):
             return step.loss_and_grads(p["image"], p["ids"], p["mask"], loss_scale=scale)
 
-        def val(batch):
-            p = ContrastiveStep.prepare(batch, self.device)
+        def val(p):
             return step.loss_only(p["image"], p["ids"], p["mask"])
 
-        return self._train_loop(1, sc, opt, self.train_loader_stage1, self.val_loader_stage1, micro, val, reducer, extra)
+        return self._train_loop(1, sc, opt, self.train_loader_stage1, self.val_loader_stage1, ContrastiveStep.prepare,
+                                micro, val, reducer, extra)
 
     def train_stage2(self) -> Dict[str, List[float]]:
         if self.train_loader_stage2 is None:
@@ -207,18 +215,17 @@ class PreferenceGuidedTrainer:
                                          group=int(self.config.get("mi355x.allreduce_layer_group", 4)))
         extra = [s for s in opt.segments if s is not reducer.seg]
 
-        def micro(batch, scale):
-            p = DPOStep.prepare(batch, self.device)
+        def micro(p, scale):
             return step.loss_and_grads(p["image"], p["seq"], loss_scale=scale)
 
-        def val(batch):
-            p = DPOStep.prepare(batch, self.device)
+        def val(p):
             return step.loss_only(p["image"], p["seq"])
 
         return self._train_loop(2, sc, opt, self.train_loader_stage2,
-                                self.val_loader_stage2 or self.train_loader_stage2, micro, val, reducer, extra)
+                                self.val_loader_stage2 or self.train_loader_stage2, DPOStep.prepare, micro, val, reducer,
+                                extra)
 
-    def _train_loop(self, stage, sc, opt, train_loader, val_loader, micro, val, reducer, extra):
+    def _train_loop(self, stage, sc, opt, train_loader, val_loader, prepare, micro, val, reducer, extra):
         metrics: Dict[str, List[float]] = {"train_loss": [], "val_loss": [], "learning_rates": []}
         self._check_loader(train_loader, f"stage {stage} training loader")
         self._check_loader(val_loader, f"stage {stage} validation loader")
@@ -229,8 +236,8 @@ class PreferenceGuidedTrainer:
         for epoch in range(first, sc["num_epochs"]):
             self.epoch = epoch
             t0 = time.time()
-            train_loss = self._run_epoch(train_loader, opt, micro, reducer, extra, sc, stage)
-            val_loss = self._validate(val_loader, val)
+            train_loss = self._run_epoch(train_loader, opt, prepare, micro, reducer, extra, sc, stage)
+            val_loss = self._validate(val_loader, prepare, val)
             lr = opt.state()["lr"]
             metrics["train_loss"].append(train_loss)
             metrics["val_loss"].append(val_loss)

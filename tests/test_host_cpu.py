@@ -9,7 +9,6 @@ from oracle import restatement as R
 from pgca_amd import REPO_ROOT
 from pgca_amd.arch import make_arch, tiny_arch
 from pgca_amd.config import Config
-from pgca_amd.engine import make_seq_batch
 from pgca_amd.params import ParamStore, model_specs
 
 
@@ -72,26 +71,6 @@ def test_store_layout_alignment_and_aliases():
     dec = st.segments["decoder"]
     pad = dec.padded(dec.fp32, "caption_decoder.lm_model.transformer.wte.weight")
     assert pad.shape[0] % 128 == 0 and float(pad[st.arch.dec_vocab:].abs().sum()) == 0.0
-
-
-def test_seq_batch_indices_are_bit_exact(golden):
-    g = golden("logprob_dpo")
-    ids, mask = torch.from_numpy(g["ids_w"]), torch.from_numpy(g["mask_w"])
-    sb = make_seq_batch(ids, mask, "cpu")
-    ref_idx = R.gather_indices(ids)                      # labels[:, 1:] (int64)
-    keep = mask[:, 1:] != 0
-    assert sb.targets.dtype == torch.int64 and torch.equal(sb.targets, ref_idx[keep])
-    assert torch.equal(sb.counts.long(), keep.sum(1))
-    b, t = torch.nonzero(keep, as_tuple=True)
-    assert torch.equal(sb.row_map.long(), b * ids.shape[1] + t) and torch.equal(sb.seq_of_row.long(), b)
-    # token log-probs gathered through row_map/targets reproduce the reference's masked sum and mean
-    logits = torch.from_numpy(g["logits_w"])
-    lp = torch.log_softmax(logits.view(-1, logits.shape[-1])[sb.row_map.long()], -1).gather(1, sb.targets[:, None])[:, 0]
-    seq = torch.zeros(ids.shape[0]).index_add_(0, sb.seq_of_row.long(), lp)
-    np.testing.assert_allclose(seq.numpy(), g["seq_sum_w"], atol=2e-5)
-    np.testing.assert_allclose((seq / sb.counts).numpy(), g["seq_mean_w"], atol=2e-5)
-    with pytest.raises(ValueError, match="no scored token"):
-        make_seq_batch(ids[:1], torch.tensor([[1] + [0] * (ids.shape[1] - 1)]), "cpu")
 
 
 def test_product_never_imports_the_oracle():

@@ -336,6 +336,64 @@ def test_patchify_patch14_pads_k(hip):
     assert float(out[:, 588:].abs().max()) == 0.0
 
 
+def test_seq_batch_prepare_is_bit_exact(hip, golden):
+    """The index work of the log-prob gather on the device (pgca_seq_batch_prepare) against the reference's own
+    gather indices (labels[:, 1:], model.py:1070 / components.py:341) - int64 targets, row map, per-sequence counts -
+    on the fixture's ragged masks, on masks with holes, on captions with a single real token, S = 2 and a large batch."""
+    from pgca_amd.engine import make_seq_batch
+    g = golden("logprob_dpo")
+    cases = [(torch.from_numpy(g["ids_w"]), torch.from_numpy(g["mask_w"]))]
+    gen = torch.Generator().manual_seed(3)
+    for Bq, S in ((7, 2), (33, 129), (512, 128), (5, 300)):
+        ids = torch.randint(0, 50257, (Bq, S), generator=gen)
+        mask = (torch.rand(Bq, S, generator=gen) < 0.7).long()          # holes, not only right padding
+        mask[0] = 1
+        if Bq > 2:
+            mask[1] = 0
+            mask[1, 0] = 1                                               # a caption with one real token: count 0
+        cases.append((ids, mask))
+    for ids, mask in cases:
+        sb = make_seq_batch(ids, mask, dev())
+        keep = mask[:, 1:] != 0
+        assert sb.targets.dtype == torch.int64 and torch.equal(sb.targets.cpu(), R.gather_indices(ids)[keep])
+        assert torch.equal(sb.counts.cpu().long(), keep.sum(1))
+        b, t = torch.nonzero(keep, as_tuple=True)
+        assert sb.n_rows == int(keep.sum())
+        assert torch.equal(sb.row_map.cpu().long(), b * ids.shape[1] + t) and torch.equal(sb.seq_of_row.cpu().long(), b)
+        assert torch.equal(sb.mask.cpu().long(), (mask != 0).long()) and torch.equal(sb.ids.cpu(), ids)
+    ids, mask = cases[0]
+    sb = make_seq_batch(ids, mask, dev())
+    logits = torch.from_numpy(g["logits_w"])
+    lp = torch.log_softmax(logits.view(-1, logits.shape[-1])[sb.row_map.cpu().long()], -1).gather(1, sb.targets.cpu()[:, None])[:, 0]
+    seq = torch.zeros(ids.shape[0]).index_add_(0, sb.seq_of_row.cpu().long(), lp)
+    np.testing.assert_allclose(seq.numpy(), g["seq_sum_w"], atol=2e-5)
+    with pytest.raises(ValueError, match="no scored token"):
+        make_seq_batch(ids[:1], torch.tensor([[1] + [0] * (ids.shape[1] - 1)]), dev())
+
+
+def test_prefetcher_feeds_prepared_batches_in_order(hip):
+    """input.BatchPrefetcher: same prepared batches as the inline path, in loader order, errors re-raised."""
+    from pgca_amd.input import BatchPrefetcher
+    from pgca_amd.steps import DPOStep
+    gen = torch.Generator().manual_seed(0)
+    raw = []
+    for i in range(5):
+        ids = torch.randint(0, 509, (4, 16), generator=gen)
+        mask = (torch.arange(16)[None] < torch.randint(3, 17, (4,), generator=gen)[:, None]).long()
+        raw.append({"image": torch.randn(2, 3, 64, 64, generator=gen), "preferred_ids": ids[:2], "rejected_ids": ids[2:],
+                    "preferred_mask": mask[:2], "rejected_mask": mask[2:]})
+    got = list(BatchPrefetcher(raw, DPOStep.prepare, dev(), depth=2))
+    assert len(got) == 5
+    torch.cuda.synchronize()
+    for r, p in zip(raw, got):
+        want = DPOStep.prepare(r, dev())
+        assert torch.equal(p["image"], want["image"]) and torch.equal(p["seq"].targets, want["seq"].targets)
+        assert torch.equal(p["seq"].row_map, want["seq"].row_map) and p["seq"].n_rows == want["seq"].n_rows
+    bad = raw[:2] + [{"image": raw[0]["image"]}]
+    with pytest.raises(KeyError):
+        list(BatchPrefetcher(bad, DPOStep.prepare, dev(), depth=2))
+
+
 def test_seq_reduce_dpo_and_row_scale(hip, golden):
     g = golden("logprob_dpo")
     B = 8
