@@ -152,6 +152,8 @@ def main():
                     help="feed every step from HOST batches through the input path (pinned staging, async H2D, device-side "
                          "index preparation, prefetch depth 2) instead of batches resident in HBM; the contract's `value` "
                          "is the resident number - this flag reports what the loop costs with a real feeder")
+    ap.add_argument("--allreduce-bf16", action="store_true",
+                    help="N > 1: bf16-compressed gradient all-reduce (half the xGMI bytes; mi355x.allreduce_bf16)")
     ap.add_argument("--ref-side-stream", action="store_true",
                     help="run the frozen reference-policy forward on a second HIP stream, concurrently with the policy's")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
@@ -179,6 +181,7 @@ def main():
     dp = DataParallel.init_from_env(os.environ.get("PGCA_BENCH_BACKEND", "nccl"))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    dp.compress_bf16 = bool(args.allreduce_bf16)
 
     for kv in args.set:
         name, _, val = kv.partition("=")
@@ -270,7 +273,12 @@ def main():
     probe.enabled = False
     dt = dp.all_reduce_max_scalar(dt, dev)
     log(f"timed region: {args.steps} steps in {dt:.3f} s -> {B * dp.world * args.steps / dt:.1f} pairs/s")
-    loss_val = float(last[0])
+    # the reported loss is the same number on every rank: Stage 1 (global negatives) is already reduced inside the
+    # step, Stage 2's local means are averaged here (outside the timed region)
+    loss_t = last[0].detach().clone().reshape(1)
+    if not stage1 and dp.world > 1:
+        loss_t = dp.all_reduce_sum(loss_t) / dp.world
+    loss_val = float(loss_t)
     st = opt.state()
 
     if dp.rank == 0:
@@ -308,6 +316,9 @@ def main():
                                      "beta 0.1, bf16 MFMA / f32 accumulate+master, AdamW+clip")),
                        "pairs_per_gpu": B, "global_pairs_per_step": B * dp.world, "seq_len": S,
                        "parallelism": f"dp{dp.world}",
+                       "grad_allreduce": ("none (1 GPU)" if dp.world == 1 else
+                                          ("bf16-compressed" if args.allreduce_bf16 else "f32") +
+                                          " SUM over RCCL, per 4 decoder layers on a side stream during backward"),
                        "dropout": (f"train mode, p={args.dropout} at the reference's sites (fused, counter-based, "
                                    "replayed in backward); reference policy in eval mode") if args.dropout > 0
                        else "identity (p=0)"},

@@ -282,6 +282,8 @@ int pgca_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, int64
                float weight_decay, float beta1, float beta2, float eps, float grad_scale, void* stream);
 /* f32 -> bf16 cast of a flat buffer (initial mirror / reference-policy snapshot). */
 int pgca_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
+/* bf16 -> f32 of a flat buffer (back from the bf16-compressed gradient all-reduce, dist.DataParallel). */
+int pgca_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream);
 /* hi/lo bf16 split of an f32 matrix along K (NT-Xent similarity at f32-grade accuracy on the bf16 MFMA GEMM,
  * reference model.py:988-990 computes the similarity in fp32): x f32 [R, P] -> y bf16 [rows_out, 3P],
  * row r = [hi | hi | lo] (pattern 0, the A operand) or [hi | lo | hi] (pattern 1, the B operand), hi = bf16(x),

@@ -420,6 +420,21 @@ __global__ void split_bf16_kernel(const float* __restrict__ x, int R, int P, int
   }
 }
 
+__global__ void cast_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x * 8;
+  for (long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8; e < n; e += stride) {
+    if (e + 8 <= n) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + e);
+      float4 a = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+      float4 b = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+      *reinterpret_cast<float4*>(y + e) = a;
+      *reinterpret_cast<float4*>(y + e + 4) = b;
+    } else {
+      for (long long k = e; k < n; ++k) y[k] = (float)x[k];
+    }
+  }
+}
+
 __global__ void axpy_kernel(const float* __restrict__ x, float alpha, float* __restrict__ y, long long n, int acc) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride)
@@ -610,6 +625,13 @@ extern "C" int pgca_cast_bf16(const float* x, void* y_bf16, int64_t n, void* str
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks_for((n + 3) / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x,
                      (bf16_t*)y_bf16, (long long)n);
   return check_launch("pgca_cast_bf16");
+}
+
+extern "C" int pgca_cast_f32(const void* x_bf16, float* y, int64_t n, void* stream) {
+  REQUIRE(x_bf16 && y && n > 0 && (((uintptr_t)x_bf16 & 15) == 0) && (((uintptr_t)y & 15) == 0), "pgca_cast_f32");
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(blocks_for((n + 7) / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x_bf16, y, (long long)n);
+  return check_launch("pgca_cast_f32");
 }
 
 extern "C" int pgca_split_bf16(const float* x, int32_t R, int32_t P, int32_t rows_out, int32_t pattern, void* y_bf16,

@@ -12,6 +12,9 @@ Replaces what the reference gets implicitly from Accelerate -> DDP -> NCCL
   (``FusedOptimizer.step(grad_scale=1/world)``) - no separate divide kernel;
 * a non-finite gradient on any rank makes the global norm non-finite on every rank (it is computed
   after the all-reduce), so the NaN-skip decision is collective-consistent without an extra flag;
+* optional bf16 compression (``compress_bf16``, config ``mi355x.allreduce_bf16``): a bucket is cast to bf16, summed on
+  the wire in bf16 and cast back - half the xGMI bytes (0.72 GB instead of 1.44 GB per step for the GPT-2-M decoder)
+  at a gradient cosine >= 0.9999 against the f32 reduction (tests/test_dist_cpu.py);
 * Stage 1 can use global negatives: one all-gather of the normalised embeddings (+ 2N floats of
   log-sum-exps in the backward), no gradient collective (``steps.ContrastiveStep``).
 """
@@ -35,8 +38,10 @@ def bucket_plan(numel: int, bucket_elems: int) -> List[Tuple[int, int]]:
 
 
 class DataParallel:
-    def __init__(self, bucket_elems: int = 64 * 1024 * 1024, group=None):
+    def __init__(self, bucket_elems: int = 64 * 1024 * 1024, group=None, compress_bf16: bool = False):
         self.group = group
+        self.compress_bf16 = bool(compress_bf16)
+        self._stage: Optional[torch.Tensor] = None   # bf16 staging of one bucket (compressed all-reduce)
         self.enabled = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.enabled else 1
         self.rank = dist.get_rank(group) if self.enabled else 0
@@ -59,6 +64,25 @@ class DataParallel:
         return DataParallel()
 
     # ---------------------------------------------------------------- gradients
+    def _reduce_bucket(self, view: torch.Tensor) -> None:
+        """SUM all-reduce of one contiguous f32 bucket (in place), optionally through a bf16 staging buffer."""
+        if not self.compress_bf16:
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        n = view.numel()
+        if self._stage is None or self._stage.numel() < n or self._stage.device != view.device:
+            self._stage = torch.empty(max(n, min(self.bucket_elems, 1 << 26)), dtype=torch.bfloat16, device=view.device)
+        st = self._stage[:n]
+        if view.is_cuda:
+            from . import hip
+            hip.cast_bf16(view, st, n)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            hip.cast_f32(st, view, n)
+        else:  # gloo rehearsal on host tensors (tests): plain torch casts, same arithmetic
+            st.copy_(view)
+            dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(st)
+
     def all_reduce_grads(self, segments: Iterable[Segment], side_stream: bool = True) -> None:
         """SUM all-reduce of every segment's flat gradient buffer, bucketed.  On GPUs the
         collectives run on a side stream that waits for the producing stream and is joined
@@ -77,7 +101,7 @@ class DataParallel:
         with ctx:
             for s in segs:
                 for a, b in bucket_plan(s.numel, self.bucket_elems):
-                    dist.all_reduce(s.grad[a:b], op=dist.ReduceOp.SUM, group=self.group)
+                    self._reduce_bucket(s.grad[a:b])
         if use_side:
             torch.cuda.current_stream().wait_stream(self._side)
 
@@ -92,9 +116,10 @@ class DataParallel:
             self._side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._side):
                 for a, b in bucket_plan(end - start, self.bucket_elems):
-                    dist.all_reduce(flat[start + a:start + b], op=dist.ReduceOp.SUM, group=self.group)
+                    self._reduce_bucket(flat[start + a:start + b])
         else:
-            dist.all_reduce(flat[start:end], op=dist.ReduceOp.SUM, group=self.group)
+            for a, b in bucket_plan(end - start, self.bucket_elems):
+                self._reduce_bucket(flat[start + a:start + b])
 
     def join(self) -> None:
         if self._side is not None:

@@ -82,6 +82,7 @@ _SIGS = {
     "pgca_scale_dev": [_vp, _i64, _vp, _vp],
     "pgca_adamw": [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _vp],
     "pgca_cast_bf16": [_vp, _vp, _i64, _vp],
+    "pgca_cast_f32": [_vp, _vp, _i64, _vp],
     "pgca_split_bf16": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pgca_axpy": [_vp, _f32, _vp, _i64, _i32, _vp],
     "pgca_gather_rows_bf16": [_vp, _vp, _i32, _i32, _vp, _vp],
@@ -377,6 +378,10 @@ def adamw(p, g, m, v, p_bf16, n, ctrl, weight_decay, beta1, beta2, eps, grad_sca
 
 def cast_bf16(x, y, n):
     _check(load().pgca_cast_bf16(_p(x), _p(y), n, _stream()), "pgca_cast_bf16")
+
+
+def cast_f32(x_bf16, y, n):
+    _check(load().pgca_cast_f32(_p(x_bf16), _p(y), n, _stream()), "pgca_cast_f32")
 
 
 def split_bf16(x, R, P, rows_out, pattern, y):

@@ -49,7 +49,8 @@ class PreferenceGuidedTrainer:
         self.train_loader_stage1, self.val_loader_stage1 = train_loader_stage1, val_loader_stage1
         self.train_loader_stage2, self.val_loader_stage2 = train_loader_stage2, val_loader_stage2
         self.accelerator = accelerator  # accepted for signature compatibility; DP is handled by pgca_amd.dist
-        self.dp = DataParallel(bucket_elems=int(config.get("mi355x.allreduce_bucket_elems", 64 * 1024 * 1024)))
+        self.dp = DataParallel(bucket_elems=int(config.get("mi355x.allreduce_bucket_elems", 64 * 1024 * 1024)),
+                               compress_bf16=bool(config.get("mi355x.allreduce_bf16", False)))
         self.device = model.device
         self.logger = logging.getLogger(__name__)
         # one accumulation value for both stages, as the reference's single Accelerator

@@ -62,7 +62,9 @@ def _worker(rank, world, port, q):
                 + torch.nn.functional.cross_entropy(txt[lo:hi] @ ia.t() / 0.5, lab, reduction="sum")) / (2 * world * 5)
         total = dp.all_reduce_sum(part.clone().reshape(1))
         mx = dp.all_reduce_max_scalar(float(rank), "cpu")
-        q.put((rank, [s.grad for s in segs], mine[0], allx, float(total), float(R.nt_xent(img, txt, 0.5)), mx))
+        # numpy: pickled BY VALUE (a torch tensor travels as a file descriptor of the sender, which may have exited)
+        q.put((rank, [s.grad.numpy() for s in segs], mine[0].numpy(), allx.numpy(), float(total),
+               float(R.nt_xent(img, txt, 0.5)), mx))
     finally:
         dist.destroy_process_group()
 
@@ -85,8 +87,57 @@ def test_two_rank_gloo_collectives():
         ref.append([torch.randn(4097, generator=g), torch.randn(333, generator=g)])
     want = [ref[0][0] + ref[1][0], ref[0][1] + ref[1][1]]
     for rank, grads, ranged, allx, total, single, mx in res:
+        grads, ranged, allx = [torch.from_numpy(g) for g in grads], torch.from_numpy(ranged), torch.from_numpy(allx)
         assert torch.allclose(grads[0], want[0]) and torch.allclose(grads[1], want[1])
         assert torch.allclose(ranged, want[0])
         assert torch.equal(allx, torch.cat([torch.zeros(3, 4), torch.ones(3, 4)]))
         assert abs(total - single) <= 1e-5       # sharded global-negative loss == single-process loss
         assert mx == 1.0
+
+
+def _worker_bf16(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dp = DataParallel(bucket_elems=3000, compress_bf16=True)
+        g = torch.Generator().manual_seed(500 + rank)
+        # gradient-like: wide dynamic range across the buffer (1e-6 .. 1)
+        x = torch.randn(10007, generator=g) * torch.logspace(-6, 0, 10007)
+        seg = FakeSeg(x.clone())
+        dp.all_reduce_grads([seg])
+        ranged = x.clone()
+        dp.all_reduce_range(ranged, 0, 10007)
+        dp.join()
+        q.put((rank, seg.grad.numpy(), ranged.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_compressed_all_reduce_keeps_the_gradient_direction():
+    """mi355x.allreduce_bf16: buckets are summed on the wire in bf16 (half the xGMI bytes).  Against the f32 sum the
+    result must keep cosine >= 0.9999 and every element within bf16 rounding of the exact sum; both ranks identical."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    xs = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(500 + r)
+        xs.append(torch.randn(10007, generator=g) * torch.logspace(-6, 0, 10007))
+    exact = (xs[0].double() + xs[1].double())
+    res = [(r, torch.from_numpy(a), torch.from_numpy(b)) for r, a, b in res]
+    for rank, grad, ranged in res:
+        for got in (grad, ranged):
+            c = float(got.double() @ exact / (got.double().norm() * exact.norm()))
+            assert c >= 0.9999, c
+            # each operand is rounded to bf16 (2^-9 relative) and so is the sum
+            bound = (xs[0].abs() + xs[1].abs()).double() * 2.0 ** -8 + exact.abs() * 2.0 ** -8 + 1e-30
+            assert bool(((got.double() - exact).abs() <= bound).all())
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
