@@ -119,19 +119,23 @@ def cpu_baseline(model, arch, S, beta, pairs):
                       f"oracle/restatement.py; {dt:.1f} s"}
 
 
-def traffic_from_profile(pairs_per_gpu: int):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    cannot be collected inside this process; tools/pmc_traffic.py turns the two passes of THIS command into
-    profiles/r01_gemm_traffic.json).  Only reported for the workload the passes were taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm_traffic.json")
+def pmc_from_profile(pairs_per_gpu: int, kernel_substr: str):
+    """HBM bytes per launch and matrix-pipe busy fraction of the dominant kernel from the committed rocprofv3 PMC passes
+    of THIS command (profiles/r02_pmc_summary.json, made by tools/pmc_summary.py: the counters cannot be collected from
+    inside the process, and FETCH_SIZE / WRITE_SIZE need separate passes).  Only reported for the workload the passes were
+    taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
         if d.get("pairs_per_gpu") != pairs_per_gpu:
             return None
-        return float(d["dominant"]["hbm_bytes"])
+        for k in d["kernels"]:
+            if kernel_substr in k["kernel"]:
+                return k
     except (OSError, KeyError, ValueError):
-        return None
+        pass
+    return None
 
 
 def main():
@@ -328,10 +332,16 @@ def main():
         }
         ps = probe.summary()
         if ps:
+            default_cfg = (not stage1 and args.vision_model == "openai/clip-vit-base-patch32"
+                           and args.text_model == "gpt2-medium" and S == 128 and not args.reference_free)
+            pmc = pmc_from_profile(B, "gemm256s_kernel<0, 1>") if default_cfg else None
             res["roofline"] = {"bound": "mfma", "achieved": ps["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ps["tflops"] / PEAK_BF16_TFLOPS, "traffic": traffic_from_profile(B),
-                               "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
-                                               "gfx950 FETCH x2 correction) of this command: profiles/r01_gemm_traffic.json",
+                               "frac": ps["tflops"] / PEAK_BF16_TFLOPS,
+                               "traffic": pmc.get("hbm_bytes") if pmc else None,
+                               "mfma_busy": pmc.get("mfma_busy") if pmc else None,
+                               "traffic_note": "HBM-side bytes per launch (read = 2 x FETCH_SIZE on gfx950, + WRITE_SIZE) and matrix-pipe "
+                                               "busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32)) from "
+                                               "separate rocprofv3 --pmc passes of this command: profiles/r02_pmc_summary.json",
                                "kernel": "gemm256s_kernel<0, 1> (every launch of the NN 256x256 LDS-DMA GEMM, phase-staggered schedule, in the timed steps)", "launches": ps["launches"],
                                "avg_launch_us": ps["avg_us"]}
         if ps and dp.world == 1:

@@ -55,14 +55,18 @@ def site_seed(base_seed: int, step: int, tower: int, layer: int, kind: int) -> i
 
 
 def dropout_multiplier(seed: int, p: float, numel: int) -> torch.Tensor:
-    """f32 tensor of 0 / 1/(1-p) for elements 0..numel-1 of the site with this seed."""
-    x = (torch.arange(numel, dtype=torch.int64) * 0x9E3779B1 + seed) & _M32
+    """f32 tensor of 0 / 1/(1-p) for elements 0..numel-1 of the site with this seed.  One hash per PAIR of elements
+    (index >> 1): the even element reads the low 16 bits, the odd one the high 16; dropped when below
+    (p * 2^32) >> 16 - the function csrc/common.h implements (``Drop::mul``)."""
+    idx = torch.arange(numel, dtype=torch.int64)
+    x = ((idx >> 1) * 0x9E3779B1 + seed) & _M32
     x = x ^ (x >> 16)
     x = (x * 0x7FEB352D) & _M32
     x = x ^ (x >> 15)
     x = (x * 0x846CA68B) & _M32
     x = x ^ (x >> 16)
-    keep = x >= min(_M32, int(p * 4294967296.0))
+    bits = torch.where((idx & 1) == 1, x >> 16, x & 0xFFFF)
+    keep = bits >= (min(_M32, int(p * 4294967296.0)) >> 16)
     return keep.to(torch.float32) / (1.0 - p)
 
 
@@ -292,6 +296,40 @@ def caption_decoder_logits(sd: SD, vision_embeddings: torch.Tensor, input_ids: t
     """... + tied LM head (modeling_gpt2.py:638-644,700): ``logits [B,S,V]``."""
     h = caption_decoder_hidden(sd, vision_embeddings, input_ids, attention_mask, heads, drop=drop)
     return h @ sd["caption_decoder.lm_model.transformer.wte.weight"].t()
+
+
+def generate_step_logits(sd: SD, vision_embeddings: torch.Tensor, ids: torch.Tensor, heads: int) -> torch.Tensor:
+    """Next-token logits of reference ``CaptionDecoder.generate`` (model.py:653-675): HF ``generate`` is started from
+    ``inputs_embeds = vision_projection(vision_features)[:, None]`` - no cross-attention, no attention_norm - and then
+    feeds ``wte`` of the tokens it produced; ``[B, V]`` for the position after ``ids`` ``[B, t]``."""
+    p = "caption_decoder"
+    pv = torch.tanh(linear(vision_embeddings.float(), sd, p + ".vision_projection.0")).unsqueeze(1)
+    emb = torch.cat([pv, sd[p + ".lm_model.transformer.wte.weight"][ids].float()], dim=1)
+    h = gpt2_trunk(sd, p + ".lm_model.transformer", emb, None, heads)
+    return h[:, -1] @ sd[p + ".lm_model.transformer.wte.weight"].t()
+
+
+def generate_greedy(sd: SD, vision_embeddings: torch.Tensor, max_length: int, heads: int, pad: int, eos: int,
+                    repetition_penalty: float = 1.0):
+    """``num_beams=1, do_sample=False`` of HF generate with the repetition-penalty processor; returns
+    (ids [B, <= max_length], per-step top-2 logit margins) - the margins tell a bf16 comparison where a tie could flip."""
+    b = vision_embeddings.shape[0]
+    ids = torch.zeros(b, 0, dtype=torch.long)
+    done = torch.zeros(b, dtype=torch.bool)
+    margins = []
+    for _ in range(max_length):
+        logits = generate_step_logits(sd, vision_embeddings, ids, heads).clone()
+        if repetition_penalty != 1.0 and ids.shape[1]:
+            seen = torch.gather(logits, 1, ids)
+            logits.scatter_(1, ids, torch.where(seen < 0, seen * repetition_penalty, seen / repetition_penalty))
+        top2 = logits.topk(2, dim=-1).values
+        margins.append(top2[:, 0] - top2[:, 1])
+        nxt = torch.where(done, torch.full((b,), pad), logits.argmax(dim=-1))
+        ids = torch.cat([ids, nxt[:, None]], dim=1)
+        done = done | (nxt == eos)
+        if bool(done.all()):
+            break
+    return ids, torch.stack(margins, dim=1)
 
 
 def model_forward(sd: SD, images: torch.Tensor, caption_ids: torch.Tensor, caption_mask: torch.Tensor,

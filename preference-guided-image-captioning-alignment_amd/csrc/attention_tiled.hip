@@ -160,15 +160,18 @@ __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __
     m_run = mx;
     float psum = 0.f;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < 8; ++mi) {
+      // attention-probability dropout (GPT-2 attn_dropout, modeling_gpt2.py:66) acts on the NORMALISED probability:
+      // the mask multiplies the numerator only, the row sum stays undropped
+      float dm[4] = {1.f, 1.f, 1.f, 1.f};
+      if (drop.on() && mi < ntile) drop.mul4(dbase + (unsigned)(k0 + mi * 16 + g * 4), dm);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float p = acc[mi][r] > -INFINITY ? __expf(acc[mi][r] - mx) : 0.f;
         psum += p;
-        // attention-probability dropout (GPT-2 attn_dropout, modeling_gpt2.py:66) acts on the NORMALISED probability:
-        // the mask multiplies the numerator only, the row sum stays undropped
-        acc[mi][r] = drop.on() ? p * drop.mul(dbase + (unsigned)(k0 + mi * 16 + g * 4 + r)) : p;
+        acc[mi][r] = p * dm[r];
       }
+    }
     l_run = l_run * alpha + psum;  // per-lane partial; the four g-lanes of a query are summed once at the end
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt)
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
                   const int q = q0 + ql + r;
                   const bool ok = kvalid && q < S && (!causal || key <= q);
                   const float pu = ok ? __expf(sa[tt][r] * scale - l4[r]) : 0.f;  // undropped probability
+                  // (the key runs along the lanes here, so each element has its own pair hash)
                   const float m = drop.on() ? drop.mul((((unsigned)b * heads + h) * S + q) * S + key) : 1.f;
                   ds[tt][r] = pu * (da[tt][r] * m - d4[r]) * scale;               // dP = dP_dropped * m
                   pd[tt][r] = pu * m;                                              // dV uses the dropped probabilities

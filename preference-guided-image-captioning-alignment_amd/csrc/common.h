@@ -62,8 +62,11 @@ __device__ __forceinline__ float dgelu_new(float x) {
 __device__ __forceinline__ float quick_gelu(float x) { return x * fast_sigmoid(1.702f * x); }
 
 // Counter-based dropout: keep(seed, idx) is a pure function of the site seed and the element's linear index, so the
-// backward replays the forward's mask without storing it.  lowbias32 integer hash; an element is dropped when
-// hash < threshold (threshold = p * 2^32).  The oracle restates the same function (oracle/restatement.py).
+// backward replays the forward's mask without storing it.  One lowbias32 hash serves a PAIR of elements (idx >> 1):
+// the even element takes the low 16 bits, the odd one the high 16; an element is dropped when its 16 bits are below
+// threshold >> 16 (threshold = p * 2^32, so p is honoured to 2^-16).  Halving the hashes matters: each costs three
+// quarter-rate 32-bit multiplies, and the GEMM epilogues, the attention kernels and the LayerNorm backward replay one
+// decision per element.  The oracle restates the same function (oracle/restatement.py: dropout_multiplier).
 __device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16;
   x *= 0x7feb352dU;
@@ -76,8 +79,27 @@ struct Drop {
   unsigned seed, threshold;  // threshold == 0 -> dropout disabled
   float scale;               // 1 / (1 - p)
   __device__ __forceinline__ bool on() const { return threshold != 0u; }
+  __device__ __forceinline__ unsigned pair_bits(unsigned pair) const { return hash32(pair * 0x9E3779B1U + seed); }
   __device__ __forceinline__ float mul(unsigned idx) const {  // multiplier of element idx: 0 or 1/(1-p)
-    return hash32(idx * 0x9E3779B1U + seed) >= threshold ? scale : 0.f;
+    const unsigned h = pair_bits(idx >> 1);
+    return ((idx & 1u) ? (h >> 16) : (h & 0xffffu)) >= (threshold >> 16) ? scale : 0.f;
+  }
+  // elements even_idx and even_idx + 1 from ONE hash (even_idx must be even)
+  __device__ __forceinline__ void mul2(unsigned even_idx, float& m0, float& m1) const {
+    const unsigned h = pair_bits(even_idx >> 1), t = threshold >> 16;
+    m0 = (h & 0xffffu) >= t ? scale : 0.f;
+    m1 = (h >> 16) >= t ? scale : 0.f;
+  }
+  // four consecutive elements: two hashes when base is even (every hot call site), three otherwise
+  __device__ __forceinline__ void mul4(unsigned base, float (&m)[4]) const {
+    if (!(base & 1u)) {
+      mul2(base, m[0], m[1]);
+      mul2(base + 2u, m[2], m[3]);
+    } else {
+      m[0] = mul(base);
+      mul2(base + 1u, m[1], m[2]);
+      m[3] = mul(base + 3u);
+    }
   }
 };
 

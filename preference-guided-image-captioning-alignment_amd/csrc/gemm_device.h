@@ -240,8 +240,11 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
   if (a.drop_threshold) {
     const Drop d{a.drop_seed, a.drop_threshold, a.drop_scale};
     const unsigned base = (unsigned)row * (unsigned)a.N + (unsigned)col;
+    float m0[4], m1[4];
+    d.mul4(base, m0);
+    d.mul4(base + 4u, m1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= d.mul(base + j);
+    for (int j = 0; j < 4; ++j) { v[j] *= m0[j]; v[j + 4] *= m1[j]; }
   }
   if (a.residual) {
     const float* p = a.residual + (size_t)row * a.ld_res + col;
@@ -387,8 +390,11 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
       }
       if (a.drop_threshold) {
         const unsigned base = (unsigned)row * (unsigned)a.N + (unsigned)col;
+        float m0[4], m1[4];
+        d.mul4(base, m0);
+        d.mul4(base + 4u, m1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= d.mul(base + j);
+        for (int j = 0; j < 4; ++j) { v[j] *= m0[j]; v[j + 4] *= m1[j]; }
       }
       if (PF == PF_RES) {
         const float4 p0 = pre[PF != PF_NONE ? i8 : 0][0], p1 = pre[PF != PF_NONE ? i8 : 0][1];

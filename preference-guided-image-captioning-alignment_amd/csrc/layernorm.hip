@@ -190,16 +190,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
           d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
           if (EXTRA) {
             if (drop_add.on()) {  // bias gradient of the GEMM whose dropped output joined this stream
-              a.x *= drop_add.mul(eidx); a.y *= drop_add.mul(eidx + 1);
-              a.z *= drop_add.mul(eidx + 2); a.w *= drop_add.mul(eidx + 3);
+              float m[4];
+              drop_add.mul4(eidx, m);
+              a.x *= m[0]; a.y *= m[1]; a.z *= m[2]; a.w *= m[3];
             }
             sa[j].x += a.x; sa[j].y += a.y; sa[j].z += a.z; sa[j].w += a.w;
           }
         }
         *reinterpret_cast<float4*>(dx_out + row * H + c) = d;
         if (drop_dx.on()) {  // the bf16 copy feeds the backward of a GEMM whose output was dropped: replay its mask
-          d.x *= drop_dx.mul(eidx); d.y *= drop_dx.mul(eidx + 1);
-          d.z *= drop_dx.mul(eidx + 2); d.w *= drop_dx.mul(eidx + 3);
+          float m[4];
+          drop_dx.mul4(eidx, m);
+          d.x *= m[0]; d.y *= m[1]; d.z *= m[2]; d.w *= m[3];
         }
         if (EXTRA) { sd[j].x += d.x; sd[j].y += d.y; sd[j].z += d.z; sd[j].w += d.w; }
         if (dx_bf) store_bf16x4(dx_bf + row * H + c, d);
@@ -284,7 +286,9 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
       y.x += t[j].x; y.y += t[j].y; y.z += t[j].z; y.w += t[j].w;
       if (drop_e.on()) {  // GPT-2 embedding dropout (modeling_gpt2.py:604)
         const unsigned e = (unsigned)m * (unsigned)H + (unsigned)c;
-        y.x *= drop_e.mul(e); y.y *= drop_e.mul(e + 1); y.z *= drop_e.mul(e + 2); y.w *= drop_e.mul(e + 3);
+        float m4[4];
+        drop_e.mul4(e, m4);
+        y.x *= m4[0]; y.y *= m4[1]; y.z *= m4[2]; y.w *= m4[3];
       }
       *reinterpret_cast<float4*>(h0 + (size_t)m * H + c) = y;
     }
@@ -349,7 +353,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
           const unsigned e = (unsigned)m * (unsigned)H + (unsigned)((j * 64 + lane) * 4);
-          dy[j].x *= drop_e.mul(e); dy[j].y *= drop_e.mul(e + 1); dy[j].z *= drop_e.mul(e + 2); dy[j].w *= drop_e.mul(e + 3);
+          float m4[4];
+          drop_e.mul4(e, m4);
+          dy[j].x *= m4[0]; dy[j].y *= m4[1]; dy[j].z *= m4[2]; dy[j].w *= m4[3];
         }
       }
       if (gamma) {
@@ -458,7 +464,9 @@ __global__ __launch_bounds__(256) void wpe_grad_kernel(const float* __restrict__
     float4 v = *reinterpret_cast<const float4*>(g + (size_t)m * H + c);
     if (drop_e.on()) {
       const unsigned e = (unsigned)m * (unsigned)H + (unsigned)c;
-      v.x *= drop_e.mul(e); v.y *= drop_e.mul(e + 1); v.z *= drop_e.mul(e + 2); v.w *= drop_e.mul(e + 3);
+      float m4[4];
+      drop_e.mul4(e, m4);
+      v.x *= m4[0]; v.y *= m4[1]; v.z *= m4[2]; v.w *= m4[3];
     }
     acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
   }

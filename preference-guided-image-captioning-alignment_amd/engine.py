@@ -591,6 +591,42 @@ class CaptionDecoderEngine:
         hip.gemm(hf, self.wte.b, M, self.V, H, hip.NT, out_f32=out)
         return out.view(sb.Bq, sb.S, self.V)
 
+    # -- generation (reference CaptionDecoder.generate, model.py:621-678) --------------------------
+    def prefix_embedding(self, emb: torch.Tensor) -> torch.Tensor:
+        """``vision_projection(vision_features)`` (Linear + Tanh, eval): the single input embedding HF's ``generate`` is
+        started from (model.py:653-655) - [B, H] f32."""
+        B = emb.shape[0]
+        H, Pd = self.arch.gpt.hidden, self.arch.proj_dim
+        emb_bf = self._buf("gen.emb_bf", (B, Pd), BF16)
+        hip.cast_bf16(emb.contiguous(), emb_bf, B * Pd)
+        pv = torch.empty(B, H, dtype=F32, device=self.ws.device)
+        hip.gemm(emb_bf, self.vp_w.b, B, H, Pd, hip.NT, epilogue=hip.EPI_TANH, bias=self.vp_b.w, out_f32=pv)
+        return pv
+
+    def next_token_logits(self, pv: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
+        """Logits of the next token given the prefix embedding ``pv`` [B, H] and the tokens generated so far ``ids``
+        [B, t] (t >= 0): GPT-2 on ``[pv, wte(ids)] + wpe`` (``inputs_embeds`` path of HF generate: no cross-attention,
+        no attention_norm - the reference feeds the projected vision vector straight to ``lm_model.generate``), causal
+        attention, ``ln_f`` + tied LM head on the last position only.  The prefix is recomputed every step (captions are
+        <= 50 tokens; no KV cache)."""
+        a = self.arch.gpt
+        B, t = ids.shape
+        H, S = a.hidden, t + 1
+        full = torch.zeros(B, S, dtype=I64, device=self.ws.device)
+        if t:
+            full[:, 1:] = ids
+        h0 = self._buf("gen.h0", (B * S, H), F32)
+        hip.embed_fwd(full, B, S, H, self.wte.w, self.wpe.w, h0)          # wte[id] + wpe[s]; row 0 is replaced below
+        h0.view(B, S, H)[:, 0, :] = pv + self.wpe.w[0]
+        hL = self.trunk.forward(h0, None, B, S, save=False)
+        rows = (torch.arange(B, dtype=I32, device=self.ws.device) * S + (S - 1)).contiguous()
+        hf = self._buf("gen.hf", (B, H), BF16)
+        hip.layernorm_fwd(hL, B, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, row_map=rows, y_bf16=hf)
+        ldv = (self.V + 3) // 4 * 4
+        out = torch.empty(B, ldv, dtype=F32, device=self.ws.device)
+        hip.gemm(hf, self.wte.b, B, self.V, H, hip.NT, out_f32=out, ld_out_f32=ldv)
+        return out[:, :self.V]
+
     # -- backward -------------------------------------------------------------------------------
     def backward(self, dseq: torch.Tensor) -> torch.Tensor:
         """dseq [Bq] = dLoss/dseq_lp.  Accumulates all decoder gradients; returns dLoss/demb [Bq, P] f32."""

@@ -6,7 +6,8 @@ error behaviour as reference ``models/model.py`` (``PreferenceGuidedCaptioningMo
 :561-619).  Tensors returned are plain device tensors: gradients are produced by the explicit
 backward schedules in ``steps.py`` (``DPOStep`` / ``ContrastiveStep``), not by autograd.
 
-Not implemented (out of the hot path): LoRA adapters.
+Not implemented (out of the hot path): LoRA adapters.  Caption generation (row 14)
+runs on the same kernels without a KV cache: ``CaptionDecoder.generate`` / ``generate_token_ids`` / ``generate_captions``.
 ``forward`` evaluates the reference's eval-mode arithmetic (no dropout); the training steps in ``steps.py`` apply
 ``model.dropout`` at the reference's train-mode sites (fused, counter-based, replayed in the backward - DESIGN.md).
 """
@@ -104,7 +105,7 @@ class CaptionDecoder:
                 attention_mask: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
                 use_cache: bool = False, return_dict: bool = True) -> Dict[str, torch.Tensor]:
         if input_ids is None:
-            raise NotImplementedError("prefix-only decoding (generation) is outside the training hot path")
+            raise ValueError("CaptionDecoder.forward needs input_ids; use generate() for prefix-only decoding")
         dev = self._o.device
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
@@ -120,6 +121,77 @@ class CaptionDecoder:
         return {"logits": logits, "loss": loss}
 
     __call__ = forward
+
+    # -- generation --------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, vision_features: torch.Tensor, max_length: int = 50, num_beams: int = 4,
+                 temperature: float = 1.0, do_sample: bool = True, top_p: float = 0.9,
+                 repetition_penalty: float = 1.1, pad_token_id: Optional[int] = None,
+                 eos_token_id: Optional[int] = None, generator: Optional[torch.Generator] = None,
+                 **kwargs) -> torch.Tensor:
+        """Reference ``CaptionDecoder.generate`` (model.py:621-678): HF ``generate`` started from the single embedding
+        ``vision_projection(vision_features)``.  Same arguments; returns generated ids ``[B, <= max_length]`` (int64,
+        padded with ``pad_token_id`` after ``eos_token_id``).  Logit processing as HF's processors: repetition penalty,
+        temperature, nucleus (top-p) filter.  ``num_beams == 1``: greedy / sampling.  ``num_beams > 1``: deterministic
+        beam search on the processed log-probabilities (HF's beam-*sample* draws from its own RNG stream and cannot be
+        reproduced; ``do_sample`` is honoured for one beam only).  Token ids default to the decoder tokenizer's
+        (model.py:509-511: [PAD] = vocab, [EOS] = vocab + 2)."""
+        if kwargs:
+            raise TypeError(f"unsupported generation arguments: {sorted(kwargs)}")
+        eng, dev = self.engine, self._o.device
+        base = self._o.arch.gpt.base_vocab
+        pad = base if pad_token_id is None else int(pad_token_id)
+        eos = base + 2 if eos_token_id is None else int(eos_token_id)
+        emb = vision_features.to(dev, F32).contiguous()
+        B, nb = emb.shape[0], max(1, int(num_beams))
+        pv = eng.prefix_embedding(emb)
+        if nb > 1:
+            pv = pv.repeat_interleave(nb, dim=0)
+        R = B * nb
+        ids = torch.zeros(R, 0, dtype=I64, device=dev)
+        done = torch.zeros(R, dtype=torch.bool, device=dev)
+        score = torch.zeros(B, nb, device=dev)
+        if nb > 1:
+            score[:, 1:] = float("-inf")                     # all beams start identical: keep one alive
+        for _ in range(int(max_length)):
+            logits = eng.next_token_logits(pv, ids).clone()
+            if repetition_penalty != 1.0 and ids.shape[1]:   # HF RepetitionPenaltyLogitsProcessor
+                seen = torch.gather(logits, 1, ids)
+                seen = torch.where(seen < 0, seen * repetition_penalty, seen / repetition_penalty)
+                logits.scatter_(1, ids, seen)
+            if nb == 1 and do_sample:
+                if temperature != 1.0:
+                    logits = logits / float(temperature)
+                if top_p < 1.0:                              # HF TopPLogitsWarper (keeps the smallest set with mass >= top_p)
+                    srt, idx = torch.sort(logits, dim=-1, descending=False)
+                    cum = torch.softmax(srt, dim=-1).cumsum(dim=-1)
+                    rm = cum <= (1.0 - float(top_p))
+                    rm[:, -1] = False
+                    logits = logits.masked_fill(rm.scatter(1, idx, rm), float("-inf"))
+                nxt = torch.multinomial(torch.softmax(logits, dim=-1), 1, generator=generator)[:, 0]
+            elif nb == 1:
+                nxt = logits.argmax(dim=-1)
+            else:
+                logp = torch.log_softmax(logits, dim=-1)
+                frozen = torch.full_like(logp, float("-inf"))
+                frozen[:, pad] = 0.0                         # a finished beam only continues with [PAD], score unchanged
+                logp = torch.where(done[:, None], frozen, logp)
+                V = logp.shape[1]
+                cand = (score.view(R, 1) + logp).view(B, nb * V)
+                score, flat = cand.topk(nb, dim=-1)
+                src = flat // V + torch.arange(B, device=dev)[:, None] * nb
+                ids, done = ids[src.view(-1)], done[src.view(-1)]
+                nxt = (flat % V).view(-1)
+            nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
+            ids = torch.cat([ids, nxt[:, None]], dim=1)
+            done = done | (nxt == eos)
+            if bool(done.all()):
+                break
+        if nb > 1:                                           # best beam per image (length penalty 1.0 as HF's default)
+            length = (ids != pad).sum(dim=1).clamp(min=1).view(B, nb).float()
+            best = (score / length).argmax(dim=-1) + torch.arange(B, device=dev) * nb
+            ids = ids[best]
+        return ids
 
 
 class PreferenceGuidedCaptioningModel:
@@ -225,5 +297,24 @@ class PreferenceGuidedCaptioningModel:
         sim = TemperatureScaledSimilarity(self.temperature, min_temp=0.0, max_temp=float("inf"))
         return sim(out["image_embeddings"], out["text_embeddings"])
 
-    def generate_captions(self, *a, **k) -> List[str]:
-        raise NotImplementedError("caption generation is outside the training hot path (SURVEY 8f N4)")
+    @torch.no_grad()
+    def generate_token_ids(self, images: torch.Tensor, **gen_kwargs) -> torch.Tensor:
+        """Images -> generated caption token ids (the tensor half of reference ``generate_captions``, model.py:883-901)."""
+        was = self.training
+        self.eval()
+        try:
+            emb = self.vision_encoder(images)["embeddings"]
+            return self.caption_decoder.generate(vision_features=emb, **gen_kwargs)
+        finally:
+            self.train(was)
+
+    def generate_captions(self, images: torch.Tensor, max_length: int = 50, num_beams: int = 4, temperature: float = 1.0,
+                          do_sample: bool = True, top_p: float = 0.9, **kwargs) -> List[str]:
+        """Reference ``generate_captions`` (model.py:855-923).  Decoding to text needs the decoder's GPT-2 tokenizer
+        (vocab.json / merges.txt are not available offline): attach one as ``model.caption_decoder.tokenizer``."""
+        tok = getattr(self.caption_decoder, "tokenizer", None)
+        if tok is None:
+            raise RuntimeError("no tokenizer attached (model.caption_decoder.tokenizer); use generate_token_ids() for ids")
+        ids = self.generate_token_ids(images, max_length=max_length, num_beams=num_beams, temperature=temperature,
+                                      do_sample=do_sample, top_p=top_p, **kwargs)
+        return [tok.decode(row.tolist(), skip_special_tokens=True).strip() for row in ids.cpu()]
