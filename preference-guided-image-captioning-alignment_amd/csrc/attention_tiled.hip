@@ -144,16 +144,18 @@ __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __
     // scale + mask; running maximum of this query (keys live on (mi, g, r))
     float mx = m_run;
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi)
+    for (int mi = 0; mi < 8; ++mi) {
+      // the 4 validity bytes of this lane's keys of tile mi in one LDS word (kms already folds key < S)
+      const unsigned kv = *reinterpret_cast<const unsigned*>(kms + mi * 16 + g * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kl = mi * 16 + g * 4 + r;
-        const int key = k0 + kl;
-        const bool ok = mi < ntile && key < S && (!causal || key <= q) && kms[kl];
+        const int key = k0 + mi * 16 + g * 4 + r;
+        const bool ok = mi < ntile && ((kv >> (8 * r)) & 1u) && (!causal || key <= q);
         const float s = ok ? acc[mi][r] * scale : -INFINITY;
         acc[mi][r] = s;
         mx = fmaxf(mx, s);
       }
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float alpha = mx > -INFINITY ? __expf(m_run - mx) : 1.f;  // exp(-inf) = 0 when this is the first live tile

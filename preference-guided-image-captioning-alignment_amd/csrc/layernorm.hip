@@ -155,6 +155,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       load_row_bf16<NV>(dyb + (size_t)m * H, H, lane, dy);
     else
       load_row_f32<NV>(dyf + (size_t)m * H, H, lane, dy);
+    // EXTRA (168 VGPRs, 3 waves/SIMD either way): the residual-stream gradient that joins here is requested with the row
+    // itself - one HBM round trip per row, not two; it is only consumed after the two wave reductions below
+    // (152 -> 128 us at 32768 x 1024).  Without EXTRA the 16 extra registers would cost a wave per SIMD (measured
+    // 95 -> 120 us), so that variant keeps the late load.
+    float4 av[EXTRA ? NV : 1];
+    if constexpr (EXTRA) {
+      if (add_to) load_row_f32<NV>(add_to + row * H, H, lane, av);
+    }
     const float mean = mean_i[m], rstd = rstd_i[m];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         d.w = rstd * (dy[j].w - c1 - xv[j].w * c2);
         const unsigned eidx = (unsigned)row * (unsigned)H + (unsigned)c;
         if (add_to) {
-          float4 a = *reinterpret_cast<const float4*>(add_to + row * H + c);
+          float4 a = EXTRA ? av[EXTRA ? j : 0] : *reinterpret_cast<const float4*>(add_to + row * H + c);
           d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
           if (EXTRA) {
             if (drop_add.on()) {  // bias gradient of the GEMM whose dropped output joined this stream
