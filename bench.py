@@ -160,6 +160,8 @@ def main():
                          "is the resident number - this flag reports what the loop costs with a real feeder")
     ap.add_argument("--allreduce-bf16", action="store_true",
                     help="N > 1: bf16-compressed gradient all-reduce (half the xGMI bytes; mi355x.allreduce_bf16)")
+    ap.add_argument("--no-wgrad-overlap", action="store_true",
+                    help="A/B: keep the grouped weight-gradient launches on the main stream (round-1 behaviour)")
     ap.add_argument("--ref-side-stream", action="store_true",
                     help="run the frozen reference-policy forward on a second HIP stream, concurrently with the policy's")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
@@ -215,6 +217,7 @@ def main():
         trunk = model.caption_decoder.engine.trunk
     opt = FusedOptimizer(segs, lr=5e-5 if stage1 else 1e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=500,
                          total_steps=100000, sched_stride=dp.world)
+    trunk.overlap_wgrad = not args.no_wgrad_overlap
     reducer = OverlappedTrunkReducer(dp, trunk, group=4)
     reducer.arm()
     log(f"model + optimizer ready ({model.store.num_params() / 1e6:.1f} M params)")

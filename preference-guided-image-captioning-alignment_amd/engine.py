@@ -226,6 +226,8 @@ class GptTrunk:
         starts.append(seg.index[prefix + ".ln_f.weight"][0])
         self.layer_ranges = [(starts[i], starts[i + 1]) for i in range(arch.layers)]
         self.grad_hook = None  # callable(layer_index) fired when a layer's gradients are complete
+        self.overlap_wgrad = True   # weight-gradient launches on a side stream (see backward)
+        self._wgrad_stream: Optional[torch.cuda.Stream] = None
 
     def _buf(self, name, shape, dtype, zero=False):
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
@@ -282,7 +284,12 @@ class GptTrunk:
     def backward(self, g: torch.Tensor, g_bf: torch.Tensor) -> torch.Tensor:
         """g / g_bf: dL/d(stream after last block) as f32 and bf16 [M, H]. Returns dL/dh0 (f32).
         Weight/bias/LN gradients are ACCUMULATED into the segment's flat gradient buffer.
-        In train mode g_bf must already carry the mask of the last layer's mlp dropout (``top_drop()``)."""
+        In train mode g_bf must already carry the mask of the last layer's mlp dropout (``top_drop()``).
+
+        The grouped weight-gradient launch of a block (192 workgroups of 128 KiB LDS: 192 of the 256 CUs for ~0.85 ms)
+        goes to a SIDE stream: nothing in the data-gradient chain of the following blocks depends on it, so their kernels
+        run on the 64 CUs it leaves idle instead of waiting behind it.  Its operands that the next block would overwrite
+        (``dpre``, ``dqkv``) alternate between two buffers by layer parity; events order the rest (see below)."""
         sv = self.saved
         assert sv is not None, "forward(save=True) must precede backward"
         a, H, I = self.arch, self.arch.hidden, self.arch.inner
@@ -293,10 +300,29 @@ class GptTrunk:
         part, partx = part4[:2], part4[2:]
         drop = sv.get("drop")
         dsite = (lambda li, kind: drop(li, kind)) if drop is not None else (lambda li, kind: None)
-        for li in range(len(self.layers) - 1, -1, -1):
+        L = len(self.layers)
+        main = torch.cuda.current_stream()
+        side = None
+        if self.overlap_wgrad and g.is_cuda:
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream()
+            side = self._wgrad_stream
+        done: Dict[int, torch.cuda.Event] = {}      # layer -> its weight gradients are complete
+
+        def settle(layer: int) -> None:
+            """Main stream may not pass this point before the weight-gradient launch of ``layer`` has finished."""
+            ev = done.pop(layer, None)
+            if ev is not None:
+                main.wait_event(ev)
+                if self.grad_hook is not None:      # the layer's gradient range is complete only now
+                    self.grad_hook(layer)
+
+        for li in range(L - 1, -1, -1):
             P, s = self.layers[li], sv[li]
+            par = "1" if (li & 1) else "0"
+            settle(li + 2)   # that launch read dpre / dqkv of this parity
             # ---- MLP: h_out = hm + c_proj(gelu(c_fc(ln2(hm))))
-            dpre = self._buf("dpre", (M, I), BF16)
+            dpre = self._buf("dpre" + par, (M, I), BF16)
             hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=s["pre"], out_bf16=dpre)
             wgrads = [(s["act"], g_bf, I, H, M, P["wpr"].g)]   # the layer's four weight gradients go out together
             dln = self._buf("dln", (M, H), BF16)
@@ -314,22 +340,35 @@ class GptTrunk:
             datt = self._buf("datt", (M, H), BF16)
             hip.gemm(g2_bf, P["wo"].b, M, H, H, hip.NT, out_bf16=datt)
             wgrads.append((s["att"], g2_bf, H, H, M, P["wo"].g))
-            dqkv = self._buf("dqkv", (M, 3 * H), BF16)
+            dqkv = self._buf("dqkv" + par, (M, 3 * H), BF16)
             hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], Bq, S, a.heads, True, dqkv,
                               drop=dsite(li, KIND_ATTN))
             hip.gemm(dqkv, P["wqkv"].b, M, H, 3 * H, hip.NT, out_bf16=dln)
             wgrads.append((s["ln1"], dqkv, H, 3 * H, M, P["wqkv"].g))
-            hip.gemm_wgrad_group(wgrads)   # one launch, whole K per tile: no split-K atomics (gemm256_group_tn_kernel)
+            # one launch, whole K per tile: no split-K atomics (gemm256_group_tn_kernel)
+            if side is not None:
+                side.wait_stream(main)              # operands above are complete
+                with torch.cuda.stream(side):
+                    hip.gemm_wgrad_group(wgrads)
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+                done[li] = ev
+            else:
+                hip.gemm_wgrad_group(wgrads)
+            # (moving these HBM-bound column sums to the side stream as well measured neutral: they stay here)
             _bias_grad(ws, M, 3 * H, 3 * H, P["bqkv"].g, x_bf16=dqkv)
             g3 = self._buf("g_c" if (li & 1) else "g_d", (M, H), F32)
             g3_bf = self._buf("gbf_c" if (li & 1) else "gbf_d", (M, H), BF16)
+            settle(li + 1)   # that launch read its incoming g_bf from the buffer g3_bf is about to overwrite
             hip.layernorm_bwd(s["hin"], M, H, P["ln1w"].w, s["m1"], s["r1"], g3, dy_bf16=dln, add_to=g2,
                               dx_bf16=g3_bf, part=part,
                               drop_dx=dsite(li - 1, KIND_RESID_MLP) if li > 0 else None)
             _ln_param_grads(part, nb, H, P["ln1w"].g, P["ln1b"].g)
             g, g_bf = g3, g3_bf
-            if self.grad_hook is not None:
+            if side is None and self.grad_hook is not None:
                 self.grad_hook(li)
+        for layer in sorted(done, reverse=True):   # layers 1 and 0: join the side stream before anything reads the gradients
+            settle(layer)
         return g
 
 

@@ -25,6 +25,9 @@ SHAPES = [  # name, layout, M, N, K, epilogue
     ("fc2_wgrad", hip.TN, 4096, 1024, 16384, "acc"),
     ("qkv_wgrad", hip.TN, 1024, 3072, 16384, "acc"),
     ("lm_head", hip.NT, 9216, 50260, 1024, "rowstats"),
+    # K-strided operands that fit the L2s / Infinity Cache: the TN main loop without HBM in the way
+    ("tn_smallK", hip.TN, 4096, 4096, 2048, "acc"),
+    ("nn_smallM", hip.NN, 4096, 4096, 2048, "bias"),
 ]
 
 
