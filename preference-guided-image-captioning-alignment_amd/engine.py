@@ -22,6 +22,7 @@ from .arch import GptArch, ModelArch, VitArch
 from .params import ParamStore, Segment, VOCAB_TILE
 
 F32, BF16, I32, I64 = torch.float32, torch.bfloat16, torch.int32, torch.int64
+ATTN_BWD_MAX_S = 512   # include/pgca_hip.h PGCA_ATTN_MAX_S
 
 
 class Workspace:
@@ -237,6 +238,11 @@ class GptTrunk:
         """h0 [Bq*S, H] f32 (already including positions) -> residual stream after the last block.
         ``drop(layer, kind)`` (optional) yields the dropout triple of a site (train mode)."""
         a, H, I = self.arch, self.arch.hidden, self.arch.inner
+        if S > a.n_pos:
+            raise ValueError(f"sequence length {S} exceeds GPT-2's {a.n_pos} learned positions")
+        if save and S > ATTN_BWD_MAX_S:
+            raise ValueError(f"training needs sequence length <= {ATTN_BWD_MAX_S} (attention backward keeps the query "
+                             f"gradients of every 128-token block in registers); got {S}")
         M = Bq * S
         L = len(self.layers)
         sv = {"M": M, "Bq": Bq, "S": S, "mask": mask, "drop": drop} if save else None

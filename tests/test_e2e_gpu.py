@@ -80,6 +80,9 @@ def test_tiny_forward_surface_matches_reference(tiny):
 
 def test_tiny_input_validation(tiny):
     _, model = tiny
+    long_ids = torch.zeros(1, 65, dtype=torch.long)          # tiny-gpt2 has 64 learned positions
+    with pytest.raises(RuntimeError, match="learned positions"):
+        model.text_encoder(long_ids, torch.ones_like(long_ids))
     with pytest.raises(ValueError, match="4D tensor"):
         model.vision_encoder(torch.zeros(3, 64, 64))
     with pytest.raises(ValueError, match="3 channels"):
