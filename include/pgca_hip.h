@@ -238,7 +238,8 @@ int pgca_dpo_loss(const float* pol_w, const float* pol_l, const float* ref_w, co
 int pgca_seq_batch_prepare(const int64_t* ids, const int64_t* mask, int32_t Bq, int32_t S, int32_t* counts,
                            int32_t* mask32, int32_t* row_map, int64_t* targets, int32_t* seq_of_row, int32_t* n_rows,
                            void* stream);
-/* row_scale[r] = dseq[seq_of_row[r]] * (mode ? 1/count : 1): dLoss/d tok_lp per compact row. */
+/* row_scale[r] = +-dseq[seq_of_row[r]] * (mode & 1 ? 1/count : 1): dLoss/d tok_lp per compact row; mode & 2 negates
+ * (the DLOGITS epilogue computes the cross-entropy form softmax - onehot, so it is fed -dLoss/dtok_lp). */
 int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,
                    int32_t mode, float* row_scale, void* stream);
 

@@ -78,7 +78,8 @@ __global__ void row_scale_kernel(const float* __restrict__ dseq, const int* __re
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   const int q = seq_of_row[r];
-  rs[r] = mode ? dseq[q] / (float)seq_count[q] : dseq[q];
+  const float v = (mode & 1) ? dseq[q] / (float)seq_count[q] : dseq[q];
+  rs[r] = (mode & 2) ? -v : v;
 }
 
 __device__ __forceinline__ float log_sigmoid(float z) {  // stable: min(z,0) - log1p(exp(-|z|))
@@ -531,7 +532,7 @@ extern "C" int pgca_seq_batch_prepare(const int64_t* ids, const int64_t* mask, i
 
 extern "C" int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,
                               int32_t mode, float* row_scale, void* stream) {
-  REQUIRE(dseq && seq_of_row && row_scale && nrows > 0 && (!mode || seq_count), "pgca_row_scale");
+  REQUIRE(dseq && seq_of_row && row_scale && nrows > 0 && (!(mode & 1) || seq_count), "pgca_row_scale");
   hipLaunchKernelGGL(row_scale_kernel, dim3((nrows + 255) / 256), dim3(256), 0, (hipStream_t)stream, dseq, seq_of_row,
                      seq_count, nrows, mode, row_scale);
   return check_launch("pgca_row_scale");

@@ -684,10 +684,9 @@ class CaptionDecoderEngine:
         M = Bq * S
         ws = self.ws
         rs = self._buf("row_scale", (Mc,), F32)
-        hip.row_scale(dseq, sb.seq_of_row, sb.counts, Mc, 1 if s["reduce"] == "mean" else 0, rs)
         # d tok_lp / d logits = onehot - softmax; the DLOGITS epilogue computes the cross-entropy form
-        # row_scale * (softmax - onehot), so it is fed -dLoss/dtok_lp
-        rs.neg_()
+        # row_scale * (softmax - onehot), so it is fed -dLoss/dtok_lp (mode bit 2 negates)
+        hip.row_scale(dseq, sb.seq_of_row, sb.counts, Mc, (1 if s["reduce"] == "mean" else 0) | 2, rs)
         # LM head: dlogits recomputed tile by tile in row chunks
         dhf = self._buf("dhf32", (Mc, H), F32, zero=True)  # f32 + accumulate: lets the K = vocab dgrad GEMM split K
         ck = min(self.LM_CHUNK, Mc)

@@ -420,6 +420,8 @@ def test_seq_reduce_dpo_and_row_scale(hip, golden):
     rs = torch.zeros(tok.numel(), device=dev())
     hip.row_scale(dseq, seq_of_row, counts.to(dev()), tok.numel(), 1, rs)
     assert torch.allclose(rs, (dseq / counts.to(dev()))[seq_of_row.long()], atol=1e-7)
+    hip.row_scale(dseq, seq_of_row, counts.to(dev()), tok.numel(), 2, rs)      # bit 2: negated (sum form)
+    assert torch.equal(rs, -dseq[seq_of_row.long()])
 
 
 def test_pool_and_normalise(hip):
