@@ -285,6 +285,30 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
   }
 }
 
+// ---- wave-private staging slab -------------------------------------------------------------------------
+// The accumulator block crosses LDS one 16-row MFMA tile row at a time: a slab of 16 x 64 f32 = 4 KiB per wave (32 KiB
+// for the eight waves - ONE stage of the 256^2 operand ring, so a persistent kernel can keep the other three stages filled
+// with the next tile's operands while it stores).  No padding: float4 group q of row r sits at group q ^ (r & 7), which makes
+// the b32 writes of the MFMA layout (two rows x 16 columns per 32 lanes: bit 4 of the column differs) and the b128 row reads
+// (the 16-lane service groups touch 16 distinct groups) conflict-free.
+constexpr int CB_LD = 64, CB_ROWS = 16;
+constexpr int CB_WAVE_FLOATS = CB_LD * CB_ROWS;  // 1024 floats = 4 KiB
+__device__ __forceinline__ int cb_idx(int row, int col) { return row * CB_LD + (col ^ ((row & 7) << 2)); }
+// slab <- tile row mi of the block (rows mi*16 .. mi*16+15)
+__device__ __forceinline__ void cb_write(float* cbuf, const f32x4 (&acc)[4][4], int mi, int lane) {
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cbuf[cb_idx((lane >> 4) * 4 + r, ni * 16 + (lane & 15))] = acc[mi][ni][r];
+}
+// 8 consecutive columns (lane & 7) * 8 .. +7 of slab row lr
+__device__ __forceinline__ void cb_read8(const float* cbuf, int lr, int lane, float (&v)[8]) {
+  const int q = (lane & 7) * 2, x = lr & 7;
+  const float4 c0 = *reinterpret_cast<const float4*>(cbuf + lr * CB_LD + ((q ^ x) << 2));
+  const float4 c1 = *reinterpret_cast<const float4*>(cbuf + lr * CB_LD + (((q + 1) ^ x) << 2));
+  v[0] = c0.x; v[1] = c0.y; v[2] = c0.z; v[3] = c0.w; v[4] = c1.x; v[5] = c1.y; v[6] = c1.z; v[7] = c1.w;
+}
+
 // ---- fast epilogue ---------------------------------------------------------------------------------
 // Interior, 16-B-aligned 64 x 64 blocks (all of the hot path).  What the general path below costs is not
 // arithmetic but LATENCY: it loads the bias / residual stream / saved activation of 8 rows, waits, finishes them,
@@ -297,9 +321,8 @@ enum { PF_NONE = 0, PF_RES = 1, PF_ACC = 2 };
 template <int EPI, int PF>
 __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem,
                                                     int mb, int cb, int lane, int wave) {
-  constexpr int LDC = 68;
   constexpr bool AUXIN = EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH;
-  float* cbuf = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+  float* cbuf = reinterpret_cast<float*>(smem) + wave * CB_WAVE_FLOATS;
   const int r8 = lane >> 3, cg = (lane & 7) * 8;
   const int col = cb + cg;
   float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
@@ -334,22 +357,15 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
   }
   const Drop d{a.drop_seed, a.drop_threshold, a.drop_scale};
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int mi = 0; mi < 4; ++mi) {
+    cb_write(cbuf, acc, mi, lane);
 #pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cbuf[(mh * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = acc[half * 2 + mh][ni][r];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int i8 = half * 4 + it;
+    for (int it = 0; it < 2; ++it) {
+      const int i8 = mi * 2 + it;
       const int lr = it * 8 + r8;
-      const int row = mb + half * 32 + lr;
-      const float4 c0 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + cg);
-      const float4 c1 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + cg + 4);
-      float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      const int row = mb + mi * 16 + lr;
+      float v[8];
+      cb_read8(cbuf, lr, lane, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= a.alpha;
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
@@ -436,13 +452,13 @@ __device__ __forceinline__ bool epilogue_fast_ok(const pgca_gemm_args& a, int mb
   return ok;
 }
 
-// The wave's 64x64 accumulator tile goes through LDS in two 32-row halves (row stride 68 floats: conflict-free
-// b32 writes in the MFMA layout, b128 reads of 8 consecutive columns), so every global access of the epilogue
-// (bias, saved activations, residual stream, outputs) is a 16-byte vector op on 128..256 contiguous bytes per row.
+// One 64 x 64 accumulator block (origin m0 + wm*64, n0 + wn*64) through the wave-private slab, 16 rows at a time, so every
+// global access of the epilogue (bias, saved activations, residual stream, outputs) is a 16-byte vector op on 128..256
+// contiguous bytes per row.  No block barriers anywhere: the slab is private to the wave and a wave's LDS operations
+// execute in order (the caller guarantees every wave has left the main loop's LDS before the first epilogue starts).
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem, int m0,
                                                int n0, int wm, int wn, int lane, int wave) {
-  constexpr int LDC = 68;
   // residual / accumulate prefetch modes exist for the plain epilogue only (where the hot path uses them)
   const bool rmw = a.residual || (a.out_f32 && a.accumulate);
   if ((EPI == PGCA_EPI_NONE || !rmw) && epilogue_fast_ok<EPI>(a, m0 + wm * 64, n0 + wn * 64)) {  // wave-uniform
@@ -450,58 +466,44 @@ __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&
     if (EPI == PGCA_EPI_NONE && a.residual) epilogue_store_fast<PGCA_EPI_NONE, PF_RES>(a, acc, smem, mb, cb, lane, wave);
     else if (EPI == PGCA_EPI_NONE && rmw) epilogue_store_fast<PGCA_EPI_NONE, PF_ACC>(a, acc, smem, mb, cb, lane, wave);
     else epilogue_store_fast<EPI, PF_NONE>(a, acc, smem, mb, cb, lane, wave);
-    // keep the block barriers of the general path below: other waves of the block may be on it
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
-    __syncthreads();
     return;
   }
-  float* cbuf = reinterpret_cast<float*>(smem) + wave * (32 * LDC);
+  float* cbuf = reinterpret_cast<float*>(smem) + wave * CB_WAVE_FLOATS;
   const int ncols = EPI == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          cbuf[(mh * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = acc[half * 2 + mh][ni][r];
-    __syncthreads();
+  for (int mi = 0; mi < 4; ++mi) {
+    cb_write(cbuf, acc, mi, lane);
     if (EPI == PGCA_EPI_NONE && a.accumulate == 2) {
       // split-K partial: f32 atomic adds, one 256-byte row segment of the tile per wave-instruction
       // (the access shape at which global_atomic_add_f32 runs at its full memory-side rate)
       const int col = n0 + wn * 64 + lane;
       if (col < a.N) {
-        for (int lr = 0; lr < 32; ++lr) {
-          const int row = m0 + wm * 64 + half * 32 + lr;
-          if (row < a.M) atomicAdd(a.out_f32 + (size_t)row * a.ld_out_f32 + col, a.alpha * cbuf[lr * LDC + lane]);
+        for (int lr = 0; lr < CB_ROWS; ++lr) {
+          const int row = m0 + wm * 64 + mi * 16 + lr;
+          if (row < a.M) atomicAdd(a.out_f32 + (size_t)row * a.ld_out_f32 + col, a.alpha * cbuf[cb_idx(lr, lane)]);
         }
       }
     } else {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int lr = it * 8 + (lane >> 3);
-      const int row = m0 + wm * 64 + half * 32 + lr;
-      const int col = n0 + wn * 64 + (lane & 7) * 8;
-      const float4 c0 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + (lane & 7) * 8);
-      const float4 c1 = *reinterpret_cast<const float4*>(cbuf + lr * LDC + (lane & 7) * 8 + 4);
-      if (row < a.M && col < ncols) {
-        float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        float lse = 0.f, rscale = 0.f;
-        long long tgt = -1;
-        if (EPI == PGCA_EPI_DLOGITS) {
-          lse = a.row_lse[row];
-          rscale = a.row_scale[row];
-          tgt = a.targets[row];
+      for (int it = 0; it < 2; ++it) {
+        const int lr = it * 8 + (lane >> 3);
+        const int row = m0 + wm * 64 + mi * 16 + lr;
+        const int col = n0 + wn * 64 + (lane & 7) * 8;
+        float v[8];
+        cb_read8(cbuf, lr, lane, v);
+        if (row < a.M && col < ncols) {
+          float lse = 0.f, rscale = 0.f;
+          long long tgt = -1;
+          if (EPI == PGCA_EPI_DLOGITS) {
+            lse = a.row_lse[row];
+            rscale = a.row_scale[row];
+            tgt = a.targets[row];
+          }
+          const int nv = ncols - col < 8 ? ncols - col : 8;
+          finish8<EPI>(a, row, col, v, nv, lse, rscale, tgt);
         }
-        const int nv = ncols - col < 8 ? ncols - col : 8;
-        finish8<EPI>(a, row, col, v, nv, lse, rscale, tgt);
       }
     }
-    }
-    __syncthreads();
   }
 }
 
