@@ -62,7 +62,8 @@ enum {
   PGCA_EPI_DTANH = 7,      /* v *= 1 - aux_in[m,n]^2     (aux_in = saved activation) */
   PGCA_EPI_ROWSTATS = 8,   /* no C written: per-row partial (max, sum exp) over this block's columns
                               + target-logit pick; fused LM head / NT-Xent (model.py:1069-1079,988-998) */
-  PGCA_EPI_DLOGITS = 9     /* v = row_scale[m] * (exp(v - row_lse[m]) - (n == target[m])); 0 for n >= N */
+  PGCA_EPI_DLOGITS = 9,    /* v = row_scale[m] * (exp(v - row_lse[m]) - (n == target[m])); 0 for n >= N */
+  PGCA_EPI_DQUICK_GELU = 10 /* v *= quick_gelu'(aux_in[m,n]) (aux_in = saved pre-activation; trainable CLIP tower) */
 };
 
 typedef struct pgca_gemm_args {
@@ -210,6 +211,11 @@ int pgca_patchify(const float* pixels, int32_t B, int32_t image, int32_t patch, 
 /* x[b, 0] = cls + pos[0]; x[b, 1+p] = patches[b, p] + pos[1+p]  (f32 [B, T, H]). */
 int pgca_vit_assemble(const float* patch_embeds, const float* cls, const float* pos, int32_t B, int32_t T,
                       int32_t H, float* x, void* stream);
+/* Backward of pgca_vit_assemble for a trainable tower (reference model.py:150-164 leaves the CLIP tower trainable unless
+ * freeze_vision_backbone): dx f32 [B, T, H] -> dpatch bf16 [B, T-1, H] (operand of the patch-embedding weight gradient),
+ * dpos[t] += sum_b dx[b, t], dcls += sum_b dx[b, 0]  (both ACCUMULATE, like every parameter gradient). */
+int pgca_vit_assemble_bwd(const float* dx, int32_t B, int32_t T, int32_t H, void* dpatch_bf16, float* dcls,
+                          float* dpos, void* stream);
 
 /* ------------------------------------------------------------------ sequence reduce + losses */
 /* tok_lp f32 [nrows] are token log-probs of the COMPACT rows; row r belongs to sequence seq_of_row[r].

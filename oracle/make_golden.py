@@ -263,6 +263,60 @@ def gen_tiny_e2e(comp, refmodel):
     np.savez_compressed(os.path.join(OUT, "tiny_e2e.npz"), **out)
 
 
+def gen_tiny_vit_grads(comp, refmodel):
+    """Gradients of the CLIP tower's own parameters on the tiny end-to-end case (same weights and inputs as
+    ``tiny_e2e.npz``): the reference only freezes the tower on request (model.py:150-164), so with the constructor
+    default every ``vision_model`` parameter trains in both stages."""
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.params import ParamStore
+    arch = tiny_arch()
+    store = ParamStore(arch, "cpu", seed=1234, frozen=())
+    sd = {k: v.clone() for k, v in store.state_dict().items()}
+    m = build_reference_model(refmodel, arch, sd)
+    e2e = np.load(os.path.join(OUT, "tiny_e2e.npz"), allow_pickle=False)
+    images = torch.from_numpy(e2e["images"])
+    ids_w, ids_l = torch.from_numpy(e2e["ids_w"]), torch.from_numpy(e2e["ids_l"])
+    mask_w, mask_l = torch.from_numpy(e2e["mask_w"]), torch.from_numpy(e2e["mask_l"])
+    named = dict(m.named_parameters(remove_duplicate=False))   # the tower is registered twice (clip_model.vision_model)
+    vm = "vision_encoder.vision_model."
+    keys = [vm + k for k in (
+        "embeddings.class_embedding", "embeddings.patch_embedding.weight", "embeddings.position_embedding.weight",
+        "pre_layrnorm.weight", "pre_layrnorm.bias", "post_layernorm.weight", "post_layernorm.bias",
+        "encoder.layers.0.self_attn.q_proj.weight", "encoder.layers.0.self_attn.k_proj.bias",
+        "encoder.layers.0.self_attn.v_proj.weight", "encoder.layers.1.self_attn.out_proj.weight",
+        "encoder.layers.1.self_attn.out_proj.bias", "encoder.layers.0.layer_norm1.weight",
+        "encoder.layers.1.layer_norm2.bias", "encoder.layers.0.mlp.fc1.weight", "encoder.layers.1.mlp.fc1.bias",
+        "encoder.layers.0.mlp.fc2.weight", "encoder.layers.1.mlp.fc2.bias")]
+    out = {"meta": meta(), "seed": np.int64(1234)}
+
+    m.zero_grad()
+    o = m(images=images, caption_ids=ids_w, caption_mask=mask_w, mode="contrastive")
+    loss1 = refmodel.ContrastiveLoss(temperature=0.5)(o["image_embeddings"], o["text_embeddings"])
+    loss1.backward()
+    assert abs(float(loss1) - float(e2e["s1_loss"])) < 1e-6
+    out["s1_loss"] = np_(loss1)
+    def put(tag):
+        for k in keys:
+            gr = named[k].grad
+            if k.endswith("patch_embedding.weight"):   # 1.5 MB whole: keep 8 output channels + two checksums
+                out[tag + "_grad_patch_rows"] = np_(gr.reshape(gr.shape[0], -1)[:8])
+                out[tag + "_grad_patch_chk"] = np.array([float(gr.double().sum()), float(gr.double().abs().sum())])
+            else:
+                out[tag + "_grad::" + k] = np_(gr)
+
+    put("s1")
+
+    m.zero_grad()
+    ow = m(images=images, caption_ids=ids_w, caption_mask=mask_w, labels=ids_w, mode="generation")
+    ol = m(images=images, caption_ids=ids_l, caption_mask=mask_l, labels=ids_l, mode="generation")
+    loss2 = refmodel.PreferenceLoss(beta=0.1)(ow["logits"], ol["logits"], ids_w, ids_l, mask_w, mask_l)
+    loss2.backward()
+    assert abs(float(loss2) - float(e2e["s2_pref_loss"])) < 1e-6
+    out["s2_pref_loss"] = np_(loss2)
+    put("s2")
+    np.savez_compressed(os.path.join(OUT, "tiny_vit_grads.npz"), **out)
+
+
 def gen_optimizer():
     """3 clipped AdamW + cosine-warm-up steps exactly as reference trainer.py:275-289,511-520 wires them."""
     from transformers import get_cosine_schedule_with_warmup
@@ -295,6 +349,7 @@ def main():
     gen_nt_xent(comp, refmodel)
     gen_logprob_dpo(comp, refmodel)
     gen_tiny_e2e(comp, refmodel)
+    gen_tiny_vit_grads(comp, refmodel)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -60,6 +60,10 @@ __device__ __forceinline__ float dgelu_new(float x) {
 }
 // HF QuickGELUActivation (transformers/activations.py:117-123)
 __device__ __forceinline__ float quick_gelu(float x) { return x * fast_sigmoid(1.702f * x); }
+__device__ __forceinline__ float dquick_gelu(float x) {
+  const float s = fast_sigmoid(1.702f * x);
+  return s + 1.702f * x * s * (1.0f - s);
+}
 
 // Counter-based dropout: keep(seed, idx) is a pure function of the site seed and the element's linear index, so the
 // backward replays the forward's mask without storing it.  One lowbias32 hash serves a PAIR of elements (idx >> 1):

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pgca_gemm_args a, in
     case PGCA_EPI_DRELU: epilogue_store<PGCA_EPI_DRELU>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
     case PGCA_EPI_DTANH: epilogue_store<PGCA_EPI_DTANH>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
     case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_DQUICK_GELU: epilogue_store<PGCA_EPI_DQUICK_GELU>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
     default: epilogue_store<PGCA_EPI_NONE>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
   }
 }
@@ -434,7 +435,8 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       set_error("pgca_gemm_bf16: no output buffer");
       return PGCA_ERR_INVALID;
     }
-    if ((a.epilogue >= PGCA_EPI_DGELU_NEW && a.epilogue <= PGCA_EPI_DTANH) && !a.aux_in) {
+    if (((a.epilogue >= PGCA_EPI_DGELU_NEW && a.epilogue <= PGCA_EPI_DTANH) || a.epilogue == PGCA_EPI_DQUICK_GELU) &&
+        !a.aux_in) {
       set_error("pgca_gemm_bf16: derivative epilogue needs aux_in");
       return PGCA_ERR_INVALID;
     }

@@ -215,7 +215,7 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
     }
-  } else if (EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH) {
+  } else if (EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH || EPI == PGCA_EPI_DQUICK_GELU) {
     const bf16_t* p = reinterpret_cast<const bf16_t*>(a.aux_in) + (size_t)row * a.ld_aux + col;
     float x[8];
     if (full && al16(p)) {
@@ -229,6 +229,7 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (EPI == PGCA_EPI_DGELU_NEW) v[j] *= dgelu_new(x[j]);
+      else if (EPI == PGCA_EPI_DQUICK_GELU) v[j] *= dquick_gelu(x[j]);
       else if (EPI == PGCA_EPI_DRELU) v[j] = x[j] > 0.f ? v[j] : 0.f;
       else v[j] *= 1.f - x[j] * x[j];
     }
@@ -321,7 +322,8 @@ enum { PF_NONE = 0, PF_RES = 1, PF_ACC = 2 };
 template <int EPI, int PF>
 __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem,
                                                     int mb, int cb, int lane, int wave) {
-  constexpr bool AUXIN = EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH;
+  constexpr bool AUXIN = EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH ||
+                         EPI == PGCA_EPI_DQUICK_GELU;
   float* cbuf = reinterpret_cast<float*>(smem) + wave * CB_WAVE_FLOATS;
   const int r8 = lane >> 3, cg = (lane & 7) * 8;
   const int col = cb + cg;
@@ -395,6 +397,7 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
         for (int j = 0; j < 8; ++j) {
           const float x = bf2f(ax[AUXIN ? i8 : 0][j]);
           if (EPI == PGCA_EPI_DGELU_NEW) v[j] *= dgelu_new(x);
+          else if (EPI == PGCA_EPI_DQUICK_GELU) v[j] *= dquick_gelu(x);
           else if (EPI == PGCA_EPI_DRELU) v[j] = x > 0.f ? v[j] : 0.f;
           else v[j] *= 1.f - x * x;
         }
@@ -521,6 +524,7 @@ __device__ __forceinline__ void run_epilogue(const pgca_gemm_args& a, f32x4 (&ac
     case PGCA_EPI_DRELU: epilogue_store<PGCA_EPI_DRELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     case PGCA_EPI_DTANH: epilogue_store<PGCA_EPI_DTANH>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_DQUICK_GELU: epilogue_store<PGCA_EPI_DQUICK_GELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
   }
 }

@@ -58,6 +58,23 @@ __global__ void vit_assemble_kernel(const float* __restrict__ pe, const float* _
   }
 }
 
+// One thread per (token, column): the batch loop reads dx with stride T*H (coalesced across columns), casts the patch rows
+// and sums over the batch for the position / class-token gradients.
+__global__ void vit_assemble_bwd_kernel(const float* __restrict__ dx, int B, int T, int H, bf16_t* __restrict__ dpatch,
+                                        float* __restrict__ dcls, float* __restrict__ dpos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * H) return;
+  const int tkn = i / H, c = i - tkn * H;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float v = dx[(size_t)b * T * H + i];
+    s += v;
+    if (tkn > 0) dpatch[((size_t)b * (T - 1) + (tkn - 1)) * H + c] = f2bf(v);
+  }
+  dpos[i] += s;
+  if (tkn == 0) dcls[c] += s;
+}
+
 // ------------------------------------------------------------------------------------ sequence reduce / DPO
 // One wave per sequence: compact rows of a sequence are contiguous [row_begin[q], row_begin[q+1]).
 __global__ void seq_reduce_kernel(const float* __restrict__ tok, const int* __restrict__ seq_of_row, int nrows,
@@ -509,6 +526,14 @@ extern "C" int pgca_vit_assemble(const float* patch_embeds, const float* cls, co
   hipLaunchKernelGGL(vit_assemble_kernel, dim3(blocks_for((long long)B * T * H, 256)), dim3(256), 0,
                      (hipStream_t)stream, patch_embeds, cls, pos, B, T, H, x);
   return check_launch("pgca_vit_assemble");
+}
+
+extern "C" int pgca_vit_assemble_bwd(const float* dx, int32_t B, int32_t T, int32_t H, void* dpatch_bf16, float* dcls,
+                                     float* dpos, void* stream) {
+  REQUIRE(dx && dpatch_bf16 && dcls && dpos && B > 0 && T > 1 && H > 0, "pgca_vit_assemble_bwd");
+  hipLaunchKernelGGL(vit_assemble_bwd_kernel, dim3((T * H + 255) / 256), dim3(256), 0, (hipStream_t)stream, dx, B, T, H,
+                     (bf16_t*)dpatch_bf16, dcls, dpos);
+  return check_launch("pgca_vit_assemble_bwd");
 }
 
 extern "C" int pgca_seq_reduce(const float* tok_lp, const int32_t* seq_of_row, int32_t nrows, int32_t nseq,

@@ -429,26 +429,38 @@ class ProjHead:
         return dx
 
 
-# ------------------------------------------------------------------------------------------ ViT (frozen)
+# ------------------------------------------------------------------------------------------ ViT
 class VisionTower:
-    """CLIP vision transformer forward (HF CLIPVisionTransformer, modeling_clip.py:200-218,353-384,
-    594-650) as called at reference model.py:222-230.  Forward only: the tower is frozen in every
-    shipped config (configs/default.yaml:23) and is run ONCE per image per step."""
+    """CLIP vision transformer (HF CLIPVisionTransformer, modeling_clip.py:200-218,353-384,594-650) as called at
+    reference model.py:222-230.  Run ONCE per image per step.
+
+    Frozen (``freeze_vision_backbone=True``, configs/default.yaml:23 - every shipped config) it is forward-only and keeps no
+    activations.  Left trainable (the constructor default, reference model.py:150-164 only freezes on request) ``forward(...,
+    save=True)`` keeps each layer's activations and ``backward(dpooled)`` accumulates the gradients of every tower
+    parameter: nn.Linear weights are ``[out, in]``, so forward is NT, the data gradient NN and the weight gradient TN with
+    the output gradient as the A operand."""
 
     def __init__(self, store: ParamStore, arch: VitArch, ws: Workspace):
         self.arch, self.ws = arch, ws
         p = "vision_encoder.vision_model"
         seg = store.seg_of(p + ".post_layernorm.weight")
         self.seg = seg
-        self.cls = seg.w(p + ".embeddings.class_embedding")
-        self.pos = seg.w(p + ".embeddings.position_embedding.weight")
-        self._wpatch_name = p + ".embeddings.patch_embedding.weight"
+        self.trainable = seg.grad is not None
+        G = (lambda n: seg.g(n)) if self.trainable else (lambda n: None)
+        self._g = G
+        self._names = dict(cls=p + ".embeddings.class_embedding", pos=p + ".embeddings.position_embedding.weight",
+                           patch=p + ".embeddings.patch_embedding.weight")
+        self.cls = seg.w(self._names["cls"])
+        self.pos = seg.w(self._names["pos"])
+        self._wpatch_name = self._names["patch"]
         # K of the patch-embedding GEMM: 3*P*P, padded with zero columns to the GEMM's 64-deep tile when it is not a
         # multiple of 8 (ViT-L/14: 588 -> 640); the padded bf16 weight is a private copy refreshed when the mirror changes
         self.patch_k = arch.patch_dim if arch.patch_dim % 8 == 0 else (arch.patch_dim + 63) // 64 * 64
         self._wpatch_pad, self._wpatch_ver = None, -1
         self.pre = (seg.w(p + ".pre_layrnorm.weight"), seg.w(p + ".pre_layrnorm.bias"))
         self.post = (seg.w(p + ".post_layernorm.weight"), seg.w(p + ".post_layernorm.bias"))
+        self.pre_g = (G(p + ".pre_layrnorm.weight"), G(p + ".pre_layrnorm.bias"))
+        self.post_g = (G(p + ".post_layernorm.weight"), G(p + ".post_layernorm.bias"))
         H = arch.hidden
         self.layers = []
         for i in range(arch.layers):
@@ -457,13 +469,23 @@ class VisionTower:
             bq_off = seg.index[q + ".self_attn.q_proj.bias"][0]
             assert seg.index[q + ".self_attn.v_proj.weight"][0] == wq_off + 2 * H * H, "q,k,v must be contiguous"
             assert seg.index[q + ".self_attn.v_proj.bias"][0] == bq_off + 2 * H
-            self.layers.append(dict(
+            L = dict(
                 wqkv=seg.bf16[wq_off:wq_off + 3 * H * H].view(3 * H, H), bqkv=seg.fp32[bq_off:bq_off + 3 * H],
                 wo=seg.wb(q + ".self_attn.out_proj.weight"), bo=seg.w(q + ".self_attn.out_proj.bias"),
                 ln1=(seg.w(q + ".layer_norm1.weight"), seg.w(q + ".layer_norm1.bias")),
                 ln2=(seg.w(q + ".layer_norm2.weight"), seg.w(q + ".layer_norm2.bias")),
                 w1=seg.wb(q + ".mlp.fc1.weight"), b1=seg.w(q + ".mlp.fc1.bias"),
-                w2=seg.wb(q + ".mlp.fc2.weight"), b2=seg.w(q + ".mlp.fc2.bias")))
+                w2=seg.wb(q + ".mlp.fc2.weight"), b2=seg.w(q + ".mlp.fc2.bias"))
+            if self.trainable:
+                L.update(
+                    g_wqkv=seg.grad[wq_off:wq_off + 3 * H * H].view(3 * H, H), g_bqkv=seg.grad[bq_off:bq_off + 3 * H],
+                    g_wo=G(q + ".self_attn.out_proj.weight"), g_bo=G(q + ".self_attn.out_proj.bias"),
+                    g_ln1=(G(q + ".layer_norm1.weight"), G(q + ".layer_norm1.bias")),
+                    g_ln2=(G(q + ".layer_norm2.weight"), G(q + ".layer_norm2.bias")),
+                    g_w1=G(q + ".mlp.fc1.weight"), g_b1=G(q + ".mlp.fc1.bias"),
+                    g_w2=G(q + ".mlp.fc2.weight"), g_b2=G(q + ".mlp.fc2.bias"))
+            self.layers.append(L)
+        self.saved: Optional[dict] = None
 
     def _patch_weight(self) -> torch.Tensor:
         """[H, patch_k] bf16 view of the conv weight (zero-padded copy when 3*P*P is not a multiple of 8)."""
@@ -477,11 +499,15 @@ class VisionTower:
             self._wpatch_ver = self.seg.bf16_version
         return self._wpatch_pad
 
-    def forward(self, pixels: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        """pixels [B,3,I,I] f32 -> (features [B,T,H] f32, pooled [B,H] f32, pooled bf16)."""
+    def forward(self, pixels: torch.Tensor, save: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """pixels [B,3,I,I] f32 -> (features [B,T,H] f32, pooled [B,H] f32, pooled bf16).
+        ``save`` (trainable tower only): keep what ``backward`` needs."""
         a, ws = self.arch, self.ws
+        save = bool(save) and self.trainable
         B = pixels.shape[0]
         H, T, G, D = a.hidden, a.tokens, a.grid, a.patch_dim
+        if save and T > ATTN_BWD_MAX_S:
+            raise ValueError(f"a trainable vision tower needs <= {ATTN_BWD_MAX_S} tokens per image; got {T}")
         M = B * T
         Kp = self.patch_k
         cols = ws.get("vit.cols", (B * G * G, Kp), BF16)
@@ -491,27 +517,119 @@ class VisionTower:
         x0 = ws.get("vit.x0", (M, H), F32)
         hip.vit_assemble(pe, self.cls, self.pos, B, T, H, x0)
         x = ws.get("vit.x", (M, H), F32)
-        hip.layernorm_fwd(x0, M, H, self.pre[0], self.pre[1], a.eps, y_f32=x)
-        y = ws.get("vit.y", (M, H), BF16)
-        qkv = ws.get("vit.qkv", (M, 3 * H), BF16)
-        att = ws.get("vit.att", (M, H), BF16)
-        act = ws.get("vit.act", (M, a.mlp), BF16)
-        for Lw in self.layers:
-            hip.layernorm_fwd(x, M, H, Lw["ln1"][0], Lw["ln1"][1], a.eps, y_bf16=y)
+        sv = None
+        if save:
+            sv = dict(B=B, M=M, cols=cols, x0=x0, m0=ws.get("vit.m0", (M,), F32), r0=ws.get("vit.r0", (M,), F32))
+            hip.layernorm_fwd(x0, M, H, self.pre[0], self.pre[1], a.eps, y_f32=x, mean=sv["m0"], rstd=sv["r0"])
+        else:
+            hip.layernorm_fwd(x0, M, H, self.pre[0], self.pre[1], a.eps, y_f32=x)
+        for li, Lw in enumerate(self.layers):
+            k = f"vit.l{li}." if save else "vit."
+            y = ws.get(k + "y", (M, H), BF16)
+            qkv = ws.get(k + "qkv", (M, 3 * H), BF16)
+            att = ws.get(k + "att", (M, H), BF16)
+            act = ws.get(k + "act", (M, a.mlp), BF16)
+            if not save:   # in place on the residual stream, nothing kept
+                hip.layernorm_fwd(x, M, H, Lw["ln1"][0], Lw["ln1"][1], a.eps, y_bf16=y)
+                hip.gemm(y, Lw["wqkv"], M, 3 * H, H, hip.NT, bias=Lw["bqkv"], out_bf16=qkv)
+                hip.attention_fwd(qkv, None, B, T, a.heads, False, att, None)
+                hip.gemm(att, Lw["wo"], M, H, H, hip.NT, bias=Lw["bo"], residual=x, out_f32=x)
+                hip.layernorm_fwd(x, M, H, Lw["ln2"][0], Lw["ln2"][1], a.eps, y_bf16=y)
+                hip.gemm(y, Lw["w1"], M, a.mlp, H, hip.NT, epilogue=hip.EPI_QUICK_GELU, bias=Lw["b1"], out_bf16=act)
+                hip.gemm(act, Lw["w2"], M, H, a.mlp, hip.NT, bias=Lw["b2"], residual=x, out_f32=x)
+                continue
+            s = dict(xin=x, y1=y, qkv=qkv, att=att, act=act,
+                     m1=ws.get(k + "m1", (M,), F32), r1=ws.get(k + "r1", (M,), F32),
+                     m2=ws.get(k + "m2", (M,), F32), r2=ws.get(k + "r2", (M,), F32),
+                     lse=ws.get(k + "lse", (B, a.heads, T), F32), xm=ws.get(k + "xm", (M, H), F32),
+                     y2=ws.get(k + "y2", (M, H), BF16), pre=ws.get(k + "pre", (M, a.mlp), BF16))
+            hip.layernorm_fwd(x, M, H, Lw["ln1"][0], Lw["ln1"][1], a.eps, y_bf16=y, mean=s["m1"], rstd=s["r1"])
             hip.gemm(y, Lw["wqkv"], M, 3 * H, H, hip.NT, bias=Lw["bqkv"], out_bf16=qkv)
-            hip.attention_fwd(qkv, None, B, T, a.heads, False, att, None)
-            hip.gemm(att, Lw["wo"], M, H, H, hip.NT, bias=Lw["bo"], residual=x, out_f32=x)
-            hip.layernorm_fwd(x, M, H, Lw["ln2"][0], Lw["ln2"][1], a.eps, y_bf16=y)
-            hip.gemm(y, Lw["w1"], M, a.mlp, H, hip.NT, epilogue=hip.EPI_QUICK_GELU, bias=Lw["b1"], out_bf16=act)
-            hip.gemm(act, Lw["w2"], M, H, a.mlp, hip.NT, bias=Lw["b2"], residual=x, out_f32=x)
+            hip.attention_fwd(qkv, None, B, T, a.heads, False, att, s["lse"])
+            hip.gemm(att, Lw["wo"], M, H, H, hip.NT, bias=Lw["bo"], residual=x, out_f32=s["xm"])
+            hip.layernorm_fwd(s["xm"], M, H, Lw["ln2"][0], Lw["ln2"][1], a.eps, y_bf16=s["y2"], mean=s["m2"], rstd=s["r2"])
+            hip.gemm(s["y2"], Lw["w1"], M, a.mlp, H, hip.NT, epilogue=hip.EPI_QUICK_GELU, bias=Lw["b1"], out_bf16=act,
+                     aux_out=s["pre"])
+            xn = ws.get(f"vit.l{li + 1}.xin", (M, H), F32)
+            hip.gemm(act, Lw["w2"], M, H, a.mlp, hip.NT, bias=Lw["b2"], residual=s["xm"], out_f32=xn)
+            sv[li] = s
+            x = xn
         cls_rows = ws.bufs.get("vit.clsrows")
         if cls_rows is None or cls_rows.numel() != B:
             cls_rows = (torch.arange(B, dtype=I32, device=ws.device) * T).contiguous()
             ws.bufs["vit.clsrows"] = cls_rows
         pooled = ws.get("vit.pooled", (B, H), F32)
         pooled_bf = ws.get("vit.pooledbf", (B, H), BF16)
-        hip.layernorm_fwd(x, B, H, self.post[0], self.post[1], a.eps, row_map=cls_rows, y_f32=pooled, y_bf16=pooled_bf)
+        if save:
+            sv.update(xL=x, cls_rows=cls_rows, mp=ws.get("vit.mp", (B,), F32), rp=ws.get("vit.rp", (B,), F32))
+            hip.layernorm_fwd(x, B, H, self.post[0], self.post[1], a.eps, row_map=cls_rows, y_f32=pooled,
+                              y_bf16=pooled_bf, mean=sv["mp"], rstd=sv["rp"])
+        else:
+            hip.layernorm_fwd(x, B, H, self.post[0], self.post[1], a.eps, row_map=cls_rows, y_f32=pooled,
+                              y_bf16=pooled_bf)
+        self.saved = sv
         return x.view(B, T, H), pooled, pooled_bf
+
+    def backward(self, dpooled: torch.Tensor) -> None:
+        """dpooled f32 [B, H] = dL/d(pooler_output).  Accumulates the gradient of every tower parameter (the ``features``
+        output carries no gradient on the reference's training paths: trainer.py:467-478,578-603 use the embeddings)."""
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError("VisionTower.backward needs forward(save=True) on a trainable tower")
+        a, ws = self.arch, self.ws
+        B, M = sv["B"], sv["M"]
+        H, T, I = a.hidden, a.tokens, a.mlp
+        nb = hip.layernorm_bwd_blocks(M)
+        part = ws.get("vit.ln_part", (2, nb, H), F32)
+        # post_layernorm saw the CLS rows only: their gradients are scattered into an otherwise zero stream gradient
+        g = ws.get("vit.g_a", (M, H), F32)
+        g.zero_()
+        nbp = hip.layernorm_bwd_blocks(B)
+        partp = ws.get("vit.ln_part_cls", (2, nbp, H), F32)
+        hip.layernorm_bwd(sv["xL"], B, H, self.post[0], sv["mp"], sv["rp"], g, dy_f32=dpooled, row_map=sv["cls_rows"],
+                          part=partp)
+        _ln_param_grads(partp, nbp, H, self.post_g[0], self.post_g[1])
+        g_bf = ws.get("vit.gbf_a", (M, H), BF16)
+        hip.cast_bf16(g, g_bf, M * H)
+        dpre = ws.get("vit.dpre", (M, I), BF16)
+        dln = ws.get("vit.dln", (M, H), BF16)
+        datt = ws.get("vit.datt", (M, H), BF16)
+        dqkv = ws.get("vit.dqkv", (M, 3 * H), BF16)
+        for li in range(len(self.layers) - 1, -1, -1):
+            Lw, s = self.layers[li], sv[li]
+            # ---- MLP: x_out = xm + fc2(quick_gelu(fc1(ln2(xm))))
+            hip.gemm(g_bf, Lw["w2"], M, I, H, hip.NN, epilogue=hip.EPI_DQUICK_GELU, aux_in=s["pre"], out_bf16=dpre)
+            hip.gemm(g_bf, s["act"], H, I, M, hip.TN, lda=H, ldb=I, out_f32=Lw["g_w2"], accumulate=True)
+            _bias_grad(ws, M, H, H, Lw["g_b2"], x_f32=g)
+            hip.gemm(dpre, Lw["w1"], M, H, I, hip.NN, out_bf16=dln)
+            hip.gemm(dpre, s["y2"], I, H, M, hip.TN, lda=I, ldb=H, out_f32=Lw["g_w1"], accumulate=True)
+            _bias_grad(ws, M, I, I, Lw["g_b1"], x_bf16=dpre)
+            g2 = ws.get("vit.g_b", (M, H), F32)
+            g2_bf = ws.get("vit.gbf_b", (M, H), BF16)
+            hip.layernorm_bwd(s["xm"], M, H, Lw["ln2"][0], s["m2"], s["r2"], g2, dy_bf16=dln, add_to=g, dx_bf16=g2_bf,
+                              part=part)
+            _ln_param_grads(part, nb, H, Lw["g_ln2"][0], Lw["g_ln2"][1])
+            # ---- attention: xm = xin + out_proj(attn(qkv(ln1(xin))))
+            hip.gemm(g2_bf, Lw["wo"], M, H, H, hip.NN, out_bf16=datt)
+            hip.gemm(g2_bf, s["att"], H, H, M, hip.TN, lda=H, ldb=H, out_f32=Lw["g_wo"], accumulate=True)
+            _bias_grad(ws, M, H, H, Lw["g_bo"], x_f32=g2)
+            hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], None, B, T, a.heads, False, dqkv)
+            hip.gemm(dqkv, Lw["wqkv"], M, H, 3 * H, hip.NN, out_bf16=dln)
+            hip.gemm(dqkv, s["y1"], 3 * H, H, M, hip.TN, lda=3 * H, ldb=H, out_f32=Lw["g_wqkv"], accumulate=True)
+            _bias_grad(ws, M, 3 * H, 3 * H, Lw["g_bqkv"], x_bf16=dqkv)
+            hip.layernorm_bwd(s["xin"], M, H, Lw["ln1"][0], s["m1"], s["r1"], g, dy_bf16=dln, add_to=g2, dx_bf16=g_bf,
+                              part=part)
+            _ln_param_grads(part, nb, H, Lw["g_ln1"][0], Lw["g_ln1"][1])
+        # ---- pre_layrnorm, embeddings
+        dx0 = ws.get("vit.g_b", (M, H), F32)
+        hip.layernorm_bwd(sv["x0"], M, H, self.pre[0], sv["m0"], sv["r0"], dx0, dy_f32=g, part=part)
+        _ln_param_grads(part, nb, H, self.pre_g[0], self.pre_g[1])
+        Np, D, Kp = B * (T - 1), a.patch_dim, self.patch_k
+        dpe = ws.get("vit.dpe", (Np, H), BF16)
+        hip.vit_assemble_bwd(dx0, B, T, H, dpe, self._g(self._names["cls"]), self._g(self._names["pos"]))
+        # conv weight [H, 3, P, P] == [H, D]: dW = dpe^t cols (the zero pad columns of ``cols`` are not read)
+        hip.gemm(dpe, sv["cols"], H, D, Np, hip.TN, lda=H, ldb=Kp, out_f32=self._g(self._names["patch"]).view(H, D),
+                 accumulate=True)
 
 
 # ------------------------------------------------------------------------------------------ caption decoder

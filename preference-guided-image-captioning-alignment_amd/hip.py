@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libpgca_hip.so")
 
 NT, NN, TN = 0, 1, 2
 EPI_NONE, EPI_GELU_NEW, EPI_QUICK_GELU, EPI_RELU, EPI_TANH = 0, 1, 2, 3, 4
-EPI_DGELU_NEW, EPI_DRELU, EPI_DTANH, EPI_ROWSTATS, EPI_DLOGITS = 5, 6, 7, 8, 9
+EPI_DGELU_NEW, EPI_DRELU, EPI_DTANH, EPI_ROWSTATS, EPI_DLOGITS, EPI_DQUICK_GELU = 5, 6, 7, 8, 9, 10
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -65,6 +65,7 @@ _SIGS = {
     "pgca_embed_bwd_blocks": [_i32, _i32],
     "pgca_patchify": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pgca_vit_assemble": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_vit_assemble_bwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pgca_seq_reduce": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
     "pgca_logits_logprob": [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
     "pgca_dpo_loss": [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
@@ -297,6 +298,11 @@ def patchify(pixels, B, image, patch, out_bf16, ld_out=None):
 def vit_assemble(patch_embeds, cls, pos, B, T, H, x):
     _check(load().pgca_vit_assemble(_p(patch_embeds), _p(cls), _p(pos), B, T, H, _p(x), _stream()),
            "pgca_vit_assemble")
+
+
+def vit_assemble_bwd(dx, B, T, H, dpatch_bf16, dcls, dpos):
+    _check(load().pgca_vit_assemble_bwd(_p(dx), B, T, H, _p(dpatch_bf16), _p(dcls), _p(dpos), _stream()),
+           "pgca_vit_assemble_bwd")
 
 
 # --------------------------------------------------------------------------- sequence reduce / losses

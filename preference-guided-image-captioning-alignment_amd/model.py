@@ -34,14 +34,14 @@ def _default_device():
 
 
 class VisionEncoder:
-    """Frozen CLIP ViT + trainable projection head (reference model.py:64-243)."""
+    """CLIP ViT (frozen on request, reference model.py:150-164) + trainable projection head (reference model.py:64-243)."""
 
     def __init__(self, owner: "PreferenceGuidedCaptioningModel"):
         self._o = owner
         self.projection_dim = owner.projection_dim
         self.feature_dim = owner.arch.vit.hidden
-        self.freeze_backbone = True
         self.tower = VisionTower(owner.store, owner.arch.vit, owner.ws)
+        self.freeze_backbone = not self.tower.trainable
         self.head = ProjHead(owner.store, "vision_encoder.projection", owner.arch.vit.hidden, owner.arch.proj_dim,
                              owner.ws, "vhead")
 
@@ -204,15 +204,12 @@ class PreferenceGuidedCaptioningModel:
                  arch: Optional[ModelArch] = None) -> None:
         if lora_config:
             raise NotImplementedError("LoRA adapters are disabled in every shipped reference config and not supported")
-        if not freeze_vision_backbone:
-            logger.warning("freeze_vision_backbone=False requested: the MI355X path keeps the CLIP tower frozen "
-                           "(forward-only kernels), as configs/default.yaml does")
         self.projection_dim = projection_dim
         self.temperature = temperature
         self.dropout = dropout
         self.device = torch.device(device) if device is not None else _default_device()
         self.arch = arch if arch is not None else make_arch(vision_model, text_model, projection_dim)
-        frozen = ["vit"] + (["text_tower"] if freeze_text_backbone else [])
+        frozen = (["vit"] if freeze_vision_backbone else []) + (["text_tower"] if freeze_text_backbone else [])
         self.store = ParamStore(self.arch, self.device, seed=seed, frozen=frozen)
         for seg in self.store.segments.values():
             seg.ensure_bf16()

@@ -150,7 +150,7 @@ class DPOStep:
         B = images.shape[0]
         assert sb.Bq == 2 * B
         P = self.store.arch.proj_dim
-        _, _, pooled_bf = self.vit.forward(images)
+        _, _, pooled_bf = self.vit.forward(images, save)   # keeps activations only when the tower is trainable
         plan = self.dropout
         plan.active = bool(save)          # save == training forward; evaluation forwards run without dropout
         emb = self.vhead.forward(pooled_bf, B, save, plan.site(TOWER_VHEAD, 0, KIND_HEAD))
@@ -194,7 +194,9 @@ class DPOStep:
         demb2 = self.dec.backward(dseq)
         demb = self.ws.get("dpo.demb", (B, self.store.arch.proj_dim), F32)
         torch.add(demb2[:B], demb2[B:], out=demb)
-        self.vhead.backward(demb, need_dx=False)
+        dpooled = self.vhead.backward(demb, need_dx=self.vit.trainable)
+        if self.vit.trainable:            # freeze_vision_backbone=False (reference model.py:150-164)
+            self.vit.backward(dpooled)
         return self.loss
 
     @torch.no_grad()
@@ -225,7 +227,7 @@ class ContrastiveStep:
 
     def forward(self, images, ids, mask, save: bool = True):
         B = images.shape[0]
-        feats_v, _, pooled_bf = self.vit.forward(images)
+        feats_v, _, pooled_bf = self.vit.forward(images, save)
         plan = self.dropout
         plan.active = bool(save)
         iemb = self.vhead.forward(pooled_bf, B, save, plan.site(TOWER_VHEAD, 0, KIND_HEAD))
@@ -256,7 +258,9 @@ class ContrastiveStep:
         dt = self.ws.get("s1.dt", (B, P), F32)
         hip.l2norm_bwd(dI, img_n, o["_in"], B, P, di)
         hip.l2norm_bwd(dT, txt_n, o["_tn"], B, P, dt)
-        self.vhead.backward(di, need_dx=False)
+        dpooled = self.vhead.backward(di, need_dx=self.vit.trainable)
+        if self.vit.trainable:
+            self.vit.backward(dpooled)
         self.text.backward(dt)
         return loss
 

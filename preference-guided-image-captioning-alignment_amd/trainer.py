@@ -94,7 +94,8 @@ class PreferenceGuidedTrainer:
     # ------------------------------------------------------------------ optimiser
     def _setup_optimizer(self, stage: int, num_training_steps: int) -> FusedOptimizer:
         sc = self.config.get(f"training.stage{stage}")
-        names = ("vision_head", "text_tower", "text_head") if stage == 1 else ("vision_head", "decoder")
+        # the CLIP tower joins when it was left trainable (reference AdamW(model.parameters()), trainer.py:275-281)
+        names = ("vit", "vision_head", "text_tower", "text_head") if stage == 1 else ("vit", "vision_head", "decoder")
         if stage == 1 and not self.model.store.segments["text_tower"].trainable:
             raise NotImplementedError("Stage 1 with freeze_text_backbone=True is not supported on the MI355X path: the "
                                       "text tower's backward always produces its weight gradients")

@@ -112,6 +112,33 @@ def test_optimizer_steps(golden):
         np.testing.assert_allclose(ps[1].numpy(), g[f"p1_{step}"], rtol=0, atol=2e-7)
 
 
+def golden_vit():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "tiny_vit_grads.npz"), allow_pickle=False)
+
+
+def check_vit_grads(sd, gv, tag, tol=1e-4):
+    """The CLIP tower left trainable (reference model.py:150-164: frozen only on request): gradients of its own
+    parameters, recorded from the reference on the same weights and inputs (oracle/make_golden.py:gen_tiny_vit_grads)."""
+    n = 0
+    for k in gv.files:
+        if not k.startswith(tag + "_grad::"):
+            continue
+        name = k[len(tag) + 7:]
+        want = gv[k]
+        got = sd[name].grad
+        if np.abs(want).max() < 1e-9:      # k_proj.bias: softmax is invariant to a shift of every key score
+            assert float(got.abs().max()) < 1e-8, name
+        else:
+            assert maxrel(got, want) <= tol, name
+        n += 1
+    pg = sd["vision_encoder.vision_model.embeddings.patch_embedding.weight"].grad
+    assert maxrel(pg.reshape(pg.shape[0], -1)[:8], gv[tag + "_grad_patch_rows"]) <= tol
+    chk = gv[tag + "_grad_patch_chk"]
+    assert abs(float(pg.double().abs().sum()) - chk[1]) <= 1e-3 * chk[1]
+    assert n == 17
+
+
 @pytest.fixture(scope="module")
 def tiny(golden):
     g = golden("tiny_e2e")
@@ -141,6 +168,7 @@ def test_tiny_stage1_end_to_end(tiny):
         if k.startswith("s1_grad::"):
             assert maxrel(sd[k[len("s1_grad::"):]].grad, g[k]) <= 1e-4, k
     assert maxrel(sd["text_encoder.text_model.wte.weight"].grad[:64], g["s1_grad_wte_rows"]) <= 1e-4
+    check_vit_grads(sd, golden_vit(), "s1")
     for k, v in sd.items():
         v.grad = None
 
@@ -168,6 +196,7 @@ def test_tiny_stage2_two_forward(tiny):
     # no gradient reaches the text tower in generation mode
     assert int(g["s2_text_tower_params_with_grad"]) == 0
     assert all(v.grad is None for k, v in sd.items() if k.startswith("text_encoder."))
+    check_vit_grads(sd, golden_vit(), "s2")
     for k, v in sd.items():
         v.grad = None
 
