@@ -19,7 +19,7 @@ VM = "vision_encoder.vision_model."
 
 
 def cos(a, b):
-    a, b = a.double().flatten().cpu(), torch.as_tensor(b).double().flatten()
+    a, b = a.double().flatten().cpu(), torch.as_tensor(b).double().flatten().cpu()
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
