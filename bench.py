@@ -166,6 +166,9 @@ def main():
                     help="run the frozen reference-policy forward on a second HIP stream, concurrently with the policy's")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="pgca_set_option dispatch knob (e.g. gemm_stagger=8); repeatable")
+    ap.add_argument("--trainable-vision", action="store_true",
+                    help="secondary line: leave the CLIP tower trainable (reference default freeze_vision_backbone=False; the "
+                         "headline config freezes it as configs/default.yaml does)")
     ap.add_argument("--stage", type=int, default=2, choices=(1, 2),
                     help="2 (default): the headline Stage-2 DPO step; 1: secondary line, Stage-1 NT-Xent step "
                          "(global negatives over the ranks when N > 1)")
@@ -198,7 +201,7 @@ def main():
     log(f"init: world={world} pairs/gpu={B} S={S}")
     arch = make_arch(args.vision_model, args.text_model, 512)
     model = PreferenceGuidedCaptioningModel(args.vision_model, args.text_model, 512, temperature=0.5,
-                                            freeze_vision_backbone=True, device=dev, seed=42)
+                                            freeze_vision_backbone=not args.trainable_vision, device=dev, seed=42)
     stage1 = args.stage == 1
     if stage1:
         ref = None
@@ -215,6 +218,8 @@ def main():
                        ref_side_stream=args.ref_side_stream, dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
         segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
         trunk = model.caption_decoder.engine.trunk
+    if args.trainable_vision:
+        segs.insert(0, model.store.segments["vit"])
     opt = FusedOptimizer(segs, lr=5e-5 if stage1 else 1e-5, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=500,
                          total_steps=100000, sched_stride=dp.world)
     trunk.overlap_wgrad = not args.no_wgrad_overlap
@@ -303,11 +308,14 @@ def main():
         flop_pair = n_fwd * seq_fwd + vit_fwd
         if stage1:  # text tower without LM head, fwd + 2 x bwd, one ViT forward (245.6 GFLOP/pair)
             flop_pair = 3 * (24 * g.hidden ** 2 * g.layers + 4 * S * g.hidden * g.layers) * S + vit_fwd
+        if args.trainable_vision:
+            flop_pair += 2 * vit_fwd     # the tower's backward
+        frozen = "trainable" if args.trainable_vision else "frozen"
         short = {"openai/clip-vit-base-patch32": "CLIP-ViT-B/32", "openai/clip-vit-base-patch16": "CLIP-ViT-B/16",
                  "openai/clip-vit-large-patch14": "CLIP-ViT-L/14", "gpt2": "GPT-2", "gpt2-medium": "GPT-2-M",
                  "gpt2-large": "GPT-2-L", "gpt2-xl": "GPT-2-XL"}
         tag = (f"{short.get(args.vision_model, args.vision_model)}+{short.get(args.text_model, args.text_model)} "
-               f"seq{S}")
+               f"seq{S}" + (" trainable tower (secondary)" if args.trainable_vision else ""))
         res = {
             "metric": (f"Stage-1 NT-Xent image-caption pairs/sec, {tag} (secondary)" if stage1
                        else f"DPO preference-pairs/sec, {tag}"),
@@ -317,11 +325,11 @@ def main():
             "synthetic, fed from HOST memory every step (pinned staging + async H2D + device-side index preparation, "
             "prefetch depth 2) - not the contract's HBM-resident number",
             "config": {"workload": (("Stage-1 NT-Xent step (tau 0.5, global negatives over the ranks), "
-                                     f"{args.vision_model} (frozen) + {args.text_model} text tower, seq_len {S}, "
+                                     f"{args.vision_model} ({frozen}) + {args.text_model} text tower, seq_len {S}, "
                                      "bf16 MFMA / f32 accumulate+master, AdamW+clip") if stage1 else
                                     ("Stage-2 DPO step, " + ("2-forward reference-free" if args.reference_free
                                                              else "4-forward policy/reference x chosen/rejected")
-                                     + f", {args.vision_model} (frozen) + {args.text_model} decoder, seq_len {S}, "
+                                     + f", {args.vision_model} ({frozen}) + {args.text_model} decoder, seq_len {S}, "
                                      "beta 0.1, bf16 MFMA / f32 accumulate+master, AdamW+clip")),
                        "pairs_per_gpu": B, "global_pairs_per_step": B * dp.world, "seq_len": S,
                        "parallelism": f"dp{dp.world}",
@@ -338,7 +346,8 @@ def main():
         ps = probe.summary()
         if ps:
             default_cfg = (not stage1 and args.vision_model == "openai/clip-vit-base-patch32"
-                           and args.text_model == "gpt2-medium" and S == 128 and not args.reference_free)
+                           and args.text_model == "gpt2-medium" and S == 128 and not args.reference_free
+                           and not args.trainable_vision)
             pmc = pmc_from_profile(B, "gemm256s_kernel<0, 1>") if default_cfg else None
             res["roofline"] = {"bound": "mfma", "achieved": ps["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                "frac": ps["tflops"] / PEAK_BF16_TFLOPS,
