@@ -217,6 +217,18 @@ int pgca_vit_assemble(const float* patch_embeds, const float* cls, const float* 
 int pgca_vit_assemble_bwd(const float* dx, int32_t B, int32_t T, int32_t H, void* dpatch_bf16, float* dcls,
                           float* dpos, void* stream);
 
+/* Image input transform of the reference's loader on the device (data/preprocessing.py:44-48,78: Resize((S, S)) ->
+ * ToTensor -> Normalize on a PIL RGB image), BIT-EXACT with the host path: images u8 [B, H, W, 3]
+ * (decoded RGB, HWC) -> Pillow's two-pass antialiased bilinear resample on 8-bit channels (22-bit fixed-point taps,
+ * round half up and clip after EACH pass; Resample.c) -> float32(v) / 255 -> (t - mean) / std -> out f32 [B, 3, S, S].
+ * x/ybounds int32 [S, 2] = (first tap, tap count), x/ycoef int32 [S, xk / yk]: Pillow's precompute_coeffs +
+ * normalize_coeffs_8bpc for W -> S and H -> S (host side: pgca_amd.input.resample_tables).  tmp u8 [B, H, S, 3] is the
+ * intermediate of the horizontal pass; resized_u8 (optional) u8 [B, S, S, 3] receives the resized image itself. */
+int pgca_image_preprocess(const uint8_t* images, int32_t B, int32_t H, int32_t W, int32_t S, const int32_t* xbounds,
+                          const int32_t* xcoef, int32_t xk, const int32_t* ybounds, const int32_t* ycoef, int32_t yk,
+                          float mean0, float mean1, float mean2, float std0, float std1, float std2, uint8_t* tmp,
+                          uint8_t* resized_u8, float* out, void* stream);
+
 /* ------------------------------------------------------------------ sequence reduce + losses */
 /* tok_lp f32 [nrows] are token log-probs of the COMPACT rows; row r belongs to sequence seq_of_row[r].
  * seq_lp[q] = sum (mode 0; components.py:357-362) or mean over the sequence's scored tokens

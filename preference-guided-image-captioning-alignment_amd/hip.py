@@ -64,6 +64,8 @@ _SIGS = {
                        _i32, _vp, _vp, _vp],
     "pgca_embed_bwd_blocks": [_i32, _i32],
     "pgca_patchify": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
+    "pgca_image_preprocess": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _f32,
+                              _vp, _vp, _vp, _vp],
     "pgca_vit_assemble": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_vit_assemble_bwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pgca_seq_reduce": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
@@ -293,6 +295,12 @@ def embed_bwd(g, ids, row_mask, B, S, H, dwte, dwpe, wte=None, attended=None, ga
 def patchify(pixels, B, image, patch, out_bf16, ld_out=None):
     ld = 3 * patch * patch if ld_out is None else ld_out
     _check(load().pgca_patchify(_p(pixels), B, image, patch, ld, _p(out_bf16), _stream()), "pgca_patchify")
+
+
+def image_preprocess(images_u8, B, H, W, S, xbounds, xcoef, ybounds, ycoef, mean, std, tmp, out, resized_u8=None):
+    _check(load().pgca_image_preprocess(_p(images_u8), B, H, W, S, _p(xbounds), _p(xcoef), xcoef.shape[1], _p(ybounds),
+                                        _p(ycoef), ycoef.shape[1], mean[0], mean[1], mean[2], std[0], std[1], std[2],
+                                        _p(tmp), _p(resized_u8), _p(out), _stream()), "pgca_image_preprocess")
 
 
 def vit_assemble(patch_embeds, cls, pos, B, T, H, x):

@@ -10,6 +10,7 @@ size the LM-head launch) happens in the feeder thread.
 """
 from __future__ import annotations
 
+import math
 import queue
 import threading
 from typing import Callable, Iterable, Iterator
@@ -17,6 +18,102 @@ from typing import Callable, Iterable, Iterator
 import torch
 
 _STOP = object()
+
+PRECISION_BITS = 32 - 8 - 2     # Pillow src/libImaging/Resample.c
+
+
+def resample_tables(in_size: int, out_size: int):
+    """Tap tables of Pillow's antialiased bilinear resample for ``in_size -> out_size`` over the whole image
+    (Resample.c ``precompute_coeffs`` with the bilinear filter, support 1, then ``normalize_coeffs_8bpc``): returns
+    ``(bounds int32 [out, 2] = (first tap, tap count), coef int32 [out, ksize])``, 22-bit fixed point.  Every float64
+    operation is done in the C code's order (sequential tap sum, divide, scale, round half away from zero by truncation) so
+    the integers are Pillow's own; ``tests/test_image_cpu.py`` holds them equal to the oracle's."""
+    import numpy as np
+    if in_size <= 0 or out_size <= 0:
+        raise ValueError("sizes must be positive")
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    xx = np.arange(out_size, dtype=np.float64)
+    center = 0.0 + (xx + 0.5) * scale
+    ss = 1.0 / filterscale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)            # C (int) truncation; values are >= -0.5
+    xmin = np.where(center - support + 0.5 < 0, 0, xmin)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    k = np.zeros((out_size, ksize), np.float64)
+    ww = np.zeros(out_size, np.float64)
+    for x in range(ksize):
+        arg = (x + xmin - center + 0.5) * ss
+        w = np.where(np.abs(arg) < 1.0, 1.0 - np.abs(arg), 0.0)
+        w = np.where(x < xmax, w, 0.0)
+        k[:, x] = w
+        ww = ww + w                                                            # sequential, as the C loop
+    nz = ww != 0.0
+    k[nz] = k[nz] / ww[nz, None]
+    fixed = np.where(k < 0, -0.5 + k * (1 << PRECISION_BITS), 0.5 + k * (1 << PRECISION_BITS)).astype(np.int64)
+    bounds = np.stack([xmin, xmax], axis=1).astype(np.int32)
+    return bounds, fixed.astype(np.int32)
+
+
+class GpuImageProcessor:
+    """The reference's ``ImageProcessor.val_transform`` (data/preprocessing.py:44-48,78; also its training transform with
+    ``augment=False``, :70) on the device: decoded RGB uint8 ``[B, H, W, 3]`` (or a list of ``[H, W, 3]`` images of any
+    sizes) -> ``Resize((S, S))`` -> ``ToTensor`` -> ``Normalize(mean, std)`` -> f32 ``[B, 3, S, S]``, bit-exact with the host
+    path (``pgca_image_preprocess``).  The random augmentations of the training transform (preprocessing.py:53-68) stay
+    with the host loader."""
+
+    def __init__(self, image_size: int = 224, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), device=None):
+        import numpy as np
+        self.image_size = int(image_size)
+        # float32 statistics, as torchvision's Normalize builds them (torch.as_tensor(mean, dtype=float32))
+        self.mean = tuple(float(np.float32(m)) for m in mean)
+        self.std = tuple(float(np.float32(s)) for s in std)
+        if any(s == 0 for s in self.std):
+            raise ValueError("std evaluated to zero after conversion to float32, leading to division by zero.")
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._tables = {}
+
+    def _table(self, n_in: int):
+        t = self._tables.get(n_in)
+        if t is None:
+            b, k = resample_tables(n_in, self.image_size)
+            t = (torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device))
+            self._tables[n_in] = t
+        return t
+
+    def process_batch(self, images: torch.Tensor, out: torch.Tensor = None, return_resized: bool = False):
+        """images uint8 [B, H, W, 3] (host or device) -> f32 [B, 3, S, S] on the device."""
+        from . import hip
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
+            raise ValueError(f"Expected uint8 images of shape (B, H, W, 3), got {images.dtype} {tuple(images.shape)}")
+        x = images.to(self.device, non_blocking=True).contiguous()
+        B, H, W, _ = x.shape
+        S = self.image_size
+        xb, xk = self._table(W)
+        yb, yk = self._table(H)
+        tmp = torch.empty((B, H, S, 3), dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((B, 3, S, S), dtype=torch.float32, device=self.device)
+        res = torch.empty((B, S, S, 3), dtype=torch.uint8, device=self.device) if return_resized else None
+        hip.image_preprocess(x, B, H, W, S, xb, xk, yb, yk, self.mean, self.std, tmp, out, resized_u8=res)
+        return (out, res) if return_resized else out
+
+    def __call__(self, images):
+        """A uint8 batch tensor, or a list of uint8 ``[H, W, 3]`` images of mixed sizes (grouped by size, order kept)."""
+        if isinstance(images, torch.Tensor):
+            return self.process_batch(images if images.dim() == 4 else images[None])
+        S = self.image_size
+        out = torch.empty((len(images), 3, S, S), dtype=torch.float32, device=self.device)
+        groups = {}
+        for i, im in enumerate(images):
+            groups.setdefault(tuple(im.shape), []).append(i)
+        for idx in groups.values():
+            batch = torch.stack([images[i] for i in idx])
+            res = self.process_batch(batch)
+            out[torch.as_tensor(idx, device=self.device)] = res
+        return out
 
 
 def _pin(x):
