@@ -240,6 +240,12 @@ int pgca_seq_reduce(const float* tok_lp, const int32_t* seq_of_row, int32_t nrow
  * out[r] = logits[row_map[r], targets[r]] - logsumexp(logits[row_map[r], 0:V]). */
 int pgca_logits_logprob(const float* logits, int32_t ld, int32_t V, const int32_t* row_map, const int64_t* targets,
                         int32_t R, float* out, void* stream);
+/* Backward of pgca_logits_logprob for callers that hold materialised logits WITH a gradient (the reference's loss objects
+ * are differentiated by autograd: model.py:1069-1083, components.py:340-362): for each compact row r,
+ * dlogits[row_map[r], 0:V] = g[r] * (onehot(targets[r]) - softmax(logits[row_map[r], 0:V])), g[r] = dLoss/d tok_lp[r];
+ * rows that score no token are not written (the caller zero-fills dlogits). */
+int pgca_logits_logprob_bwd(const float* logits, int32_t ld, int32_t V, const int32_t* row_map, const int64_t* targets,
+                            const float* g, int32_t R, float* dlogits, void* stream);
 /* DPO / preference loss over B pairs (components.py:210-231, model.py:1047-1048).
  * pol_w/pol_l/ref_w/ref_l f32 [B] (ref_* may be NULL = reference-free).
  * loss[0] = mean loss; dpol_w/dpol_l [B] = dLoss/dpol (f32), all zero when the loss is not finite (the reference skips

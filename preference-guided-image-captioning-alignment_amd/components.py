@@ -53,6 +53,37 @@ class TemperatureScaledSimilarity:
     forward = __call__
 
 
+class _NormalisedNTXentFn(torch.autograd.Function):
+    """components.py:129-145: normalise, similarity / clamped tau, symmetric cross-entropy - with the gradient w.r.t. the
+    UN-normalised inputs (NT-Xent backward -> l2-normalise backward) for ``loss.backward()`` callers."""
+
+    @staticmethod
+    def forward(ctx, vis, txt, owner):
+        dev = _dev(vis)
+        v, t = vis.detach().to(F32).contiguous(), txt.detach().to(F32).contiguous()
+        (B, P) = v.shape
+        if owner._eng is None or owner._eng.ws.device != dev or owner._eng.P != P:
+            owner._eng = NTXentEngine(Workspace(dev), P, owner.similarity.clamped, tag="comp.ntx")
+        eng = owner._eng
+        eng.tau = owner.similarity.clamped
+        vn, vnorm = eng.normalize(v, "i")
+        tn, tnorm = eng.normalize(t, "t")
+        loss, _, _ = eng.forward(vn, tn)
+        scale = float(B) if owner.reduction == "sum" else 1.0
+        if any(ctx.needs_input_grad[:2]):
+            dI, dT = eng.backward(loss_scale=scale)
+            dv, dt = torch.empty_like(v), torch.empty_like(t)
+            hip.l2norm_bwd(dI, vn, vnorm, B, P, dv)
+            hip.l2norm_bwd(dT, tn, tnorm, t.shape[0], P, dt)
+            ctx.save_for_backward(dv, dt)
+        return loss[0] * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        dv, dt = ctx.saved_tensors
+        return (dv * g if ctx.needs_input_grad[0] else None, dt * g if ctx.needs_input_grad[1] else None, None)
+
+
 class ContrastiveLoss:
     def __init__(self, temperature: float = 0.5, reduction: str = "mean"):
         if reduction not in ("mean", "sum"):
@@ -62,13 +93,6 @@ class ContrastiveLoss:
         self._eng = None
 
     def __call__(self, vision_embeds: torch.Tensor, text_embeds: torch.Tensor) -> torch.Tensor:
-        dev = _dev(vision_embeds)
-        v, t = _normalised(vision_embeds), _normalised(text_embeds)
-        if self._eng is None or self._eng.ws.device != dev or self._eng.P != v.shape[1]:
-            self._eng = NTXentEngine(Workspace(dev), v.shape[1], self.similarity.clamped, tag="comp.ntx")
-        self._eng.tau = self.similarity.clamped
-        loss, _, _ = self._eng.forward(v, t)
-        out = loss[0].clone()
-        return out * v.shape[0] if self.reduction == "sum" else out
+        return _NormalisedNTXentFn.apply(vision_embeds, text_embeds, self)
 
     forward = __call__

@@ -488,6 +488,28 @@ __global__ void logits_logprob_kernel(const float* __restrict__ logits, int ld, 
   if (lane == 0) out[r] = row[targets[r]] - (mx + __logf(s));
 }
 
+// Backward of the gather above on materialised logits: dlogits[row_map[r], :] = g[r] * (onehot(target) - softmax(row));
+// one wave per scored row; rows that score no token keep the zeros the caller put there.
+__global__ void logits_logprob_bwd_kernel(const float* __restrict__ logits, int ld, int V, const int* __restrict__ row_map,
+                                          const long long* __restrict__ targets, const float* __restrict__ g, int R,
+                                          float* __restrict__ dlogits) {
+  const int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (r >= R) return;
+  const size_t off = (size_t)(row_map ? row_map[r] : r) * ld;
+  const float* row = logits + off;
+  float* drow = dlogits + off;
+  float mx = -INFINITY;
+  for (int c = lane; c < V; c += 64) mx = fmaxf(mx, row[c]);
+  mx = wave_max(mx);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += __expf(row[c] - mx);
+  s = wave_sum(s);
+  const float lse = mx + __logf(s), gr = g[r];
+  const int tgt = (int)targets[r];
+  for (int c = lane; c < V; c += 64) drow[c] = gr * ((c == tgt ? 1.f : 0.f) - __expf(row[c] - lse));
+}
+
 inline int blocks_for(long long work, int per_block, int cap = 4096) {
   long long b = (work + per_block - 1) / per_block;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -691,4 +713,13 @@ extern "C" int pgca_logits_logprob(const float* logits, int32_t ld, int32_t V, c
   hipLaunchKernelGGL(logits_logprob_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, V,
                      row_map, (const long long*)targets, R, out);
   return check_launch("pgca_logits_logprob");
+}
+
+extern "C" int pgca_logits_logprob_bwd(const float* logits, int32_t ld, int32_t V, const int32_t* row_map,
+                                       const int64_t* targets, const float* g, int32_t R, float* dlogits, void* stream) {
+  REQUIRE(logits && targets && g && dlogits && ld >= V && V > 0 && R >= 0, "pgca_logits_logprob_bwd");
+  if (R == 0) return PGCA_OK;
+  hipLaunchKernelGGL(logits_logprob_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, V,
+                     row_map, (const long long*)targets, g, R, dlogits);
+  return check_launch("pgca_logits_logprob_bwd");
 }

@@ -70,6 +70,7 @@ _SIGS = {
     "pgca_vit_assemble_bwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pgca_seq_reduce": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
     "pgca_logits_logprob": [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp],
+    "pgca_logits_logprob_bwd": [_vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp],
     "pgca_dpo_loss": [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_row_scale": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "pgca_seq_batch_prepare": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -317,6 +318,11 @@ def vit_assemble_bwd(dx, B, T, H, dpatch_bf16, dcls, dpos):
 def seq_reduce(tok_lp, seq_of_row, nrows, nseq, seq_count, mode, seq_lp):
     _check(load().pgca_seq_reduce(_p(tok_lp), _p(seq_of_row), nrows, nseq, _p(seq_count), mode, _p(seq_lp),
                                   _stream()), "pgca_seq_reduce")
+
+
+def logits_logprob_bwd(logits, ld, V, row_map, targets, g, R, dlogits):
+    _check(load().pgca_logits_logprob_bwd(_p(logits), ld, V, _p(row_map), _p(targets), _p(g), R, _p(dlogits), _stream()),
+           "pgca_logits_logprob_bwd")
 
 
 def logits_logprob(logits, ld, V, row_map, targets, R, out):

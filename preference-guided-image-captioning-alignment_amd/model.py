@@ -33,6 +33,43 @@ def _default_device():
     return torch.device("cuda", torch.cuda.current_device())
 
 
+class ModuleView:
+    """What the reference exposes as ``nn.Module`` attributes (``vision_model``, ``projection``, ``text_model``,
+    ``lm_model``, ``cross_attention`` ... - reference tests/test_model.py:30-35,74-88,112-118,220-226 touch them): a
+    read-only view of the parameters under one prefix of the flat store, with ``requires_grad`` telling whether their
+    segment trains (the reference's ``_freeze_backbone``, model.py:150-164,354-368)."""
+
+    def __init__(self, store, prefix: str):
+        self._store, self._prefix = store, prefix.rstrip(".") + "."
+
+    def named_parameters(self):
+        out = []
+        for seg in self._store.segments.values():
+            for n in seg.index:
+                if n.startswith(self._prefix):
+                    t = seg.w(n)
+                    t.requires_grad_(bool(seg.trainable))
+                    out.append((n[len(self._prefix):], t))
+        return out
+
+    def parameters(self):
+        return [t for _, t in self.named_parameters()]
+
+    def state_dict(self):
+        return {n: t.detach() for n, t in self.named_parameters()}
+
+
+class DecoderOutput(dict):
+    """``CaptionDecoder.forward`` result: HF's ``CausalLMOutputWithCrossAttentions`` is read both as ``out.logits``
+    (reference model.py:836, tests/test_model.py:241-243) and as ``out["logits"]``."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
 class VisionEncoder:
     """CLIP ViT (frozen on request, reference model.py:150-164) + trainable projection head (reference model.py:64-243)."""
 
@@ -44,6 +81,15 @@ class VisionEncoder:
         self.freeze_backbone = not self.tower.trainable
         self.head = ProjHead(owner.store, "vision_encoder.projection", owner.arch.vit.hidden, owner.arch.proj_dim,
                              owner.ws, "vhead")
+        self.vision_model = ModuleView(owner.store, "vision_encoder.vision_model")
+        self.projection = ModuleView(owner.store, "vision_encoder.projection")
+        self._all = ModuleView(owner.store, "vision_encoder")
+
+    def parameters(self):
+        return self._all.parameters()
+
+    def named_parameters(self):
+        return self._all.named_parameters()
 
     def forward(self, pixel_values: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         if pixel_values.dim() != 4:
@@ -69,6 +115,17 @@ class TextEncoder:
         self.projection_dim = owner.projection_dim
         self.feature_dim = owner.arch.gpt.hidden
         self.engine = TextTowerEngine(owner.store, owner.arch, owner.ws, "text")
+        self.freeze_backbone = not owner.store.segments["text_tower"].trainable
+        self.text_model = ModuleView(owner.store, "text_encoder.text_model")
+        self.projection = ModuleView(owner.store, "text_encoder.projection")
+        self.tokenizer = None     # GPT-2 vocab/merges files are not bundled; attach a tokenizer to decode / encode text
+        self._all = ModuleView(owner.store, "text_encoder")
+
+    def parameters(self):
+        return self._all.parameters()
+
+    def named_parameters(self):
+        return self._all.named_parameters()
 
     def forward(self, input_ids: torch.Tensor, attention_mask: torch.Tensor,
                 return_hidden_states: bool = False) -> Dict[str, torch.Tensor]:
@@ -83,10 +140,19 @@ class TextEncoder:
             dev = self._o.device
             ids = input_ids.to(dev, I64).contiguous()
             mask = (attention_mask != 0).to(I32).to(dev).contiguous()
-            feats, pooled, emb = self.engine.forward(ids, mask, save=False)
+            feats, pooled, emb = self.engine.forward(ids, mask, save=bool(return_hidden_states))
         except Exception as e:  # reference model.py:458-460
             raise RuntimeError(f"Text encoding failed: {e}") from e
-        return {"features": feats, "embeddings": emb, "pooled_output": pooled}
+        result = {"features": feats, "embeddings": emb, "pooled_output": pooled}
+        if return_hidden_states:
+            # HF GPT2Model(output_hidden_states=True) (modeling_gpt2.py:596-634): the input embeddings, the output of every
+            # block but the last, then the last block's output AFTER ln_f (== features)
+            B, S = ids.shape
+            sv = self.engine.trunk.saved
+            hs = [sv[li]["hin"].view(B, S, -1).clone() for li in range(len(self.engine.trunk.layers))]
+            result["hidden_states"] = tuple(hs + [feats.clone()])
+            self.engine.trunk.saved = self.engine.saved = None
+        return result
 
     __call__ = forward
 
@@ -100,13 +166,29 @@ class CaptionDecoder:
         self.vocab_size = owner.arch.dec_vocab
         self.vision_feature_dim = owner.projection_dim
         self.engine = CaptionDecoderEngine(owner.store, owner.arch, owner.ws, "pol")
+        self.lm_model = ModuleView(owner.store, "caption_decoder.lm_model")
+        self.vision_projection = ModuleView(owner.store, "caption_decoder.vision_projection")
+        self.cross_attention = ModuleView(owner.store, "caption_decoder.cross_attention")
+        self.attention_norm = ModuleView(owner.store, "caption_decoder.attention_norm")
+        self.tokenizer = None
+        self._all = ModuleView(owner.store, "caption_decoder")
+
+    def parameters(self):
+        return self._all.parameters()
+
+    def named_parameters(self):
+        return self._all.named_parameters()
 
     def forward(self, vision_features: torch.Tensor, input_ids: Optional[torch.Tensor] = None,
                 attention_mask: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None,
                 use_cache: bool = False, return_dict: bool = True) -> Dict[str, torch.Tensor]:
-        if input_ids is None:
-            raise ValueError("CaptionDecoder.forward needs input_ids; use generate() for prefix-only decoding")
         dev = self._o.device
+        if input_ids is None:
+            # generation mode (reference model.py:611-617): the LM runs on the projected vision vector alone -> [B, 1, V]
+            vf = vision_features.to(dev, F32).contiguous()
+            pv = self.engine.prefix_embedding(vf)
+            empty = torch.zeros(vf.shape[0], 0, dtype=I64, device=dev)
+            return DecoderOutput(logits=self.engine.next_token_logits(pv, empty)[:, None, :].contiguous(), loss=None)
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
         sb = make_seq_batch(input_ids, attention_mask, dev)
@@ -118,7 +200,7 @@ class CaptionDecoder:
             tok = torch.empty(full.n_rows, dtype=F32, device=dev)
             hip.logits_logprob(logits, V, V, full.row_map, full.targets, full.n_rows, tok)
             loss = -tok.mean()
-        return {"logits": logits, "loss": loss}
+        return DecoderOutput(logits=logits, loss=loss)
 
     __call__ = forward
 
@@ -209,6 +291,7 @@ class PreferenceGuidedCaptioningModel:
         self.dropout = dropout
         self.device = torch.device(device) if device is not None else _default_device()
         self.arch = arch if arch is not None else make_arch(vision_model, text_model, projection_dim)
+        self.projection_dim = self.arch.proj_dim      # an explicit ``arch`` carries its own projection width
         frozen = (["vit"] if freeze_vision_backbone else []) + (["text_tower"] if freeze_text_backbone else [])
         self.store = ParamStore(self.arch, self.device, seed=seed, frozen=frozen)
         for seg in self.store.segments.values():
