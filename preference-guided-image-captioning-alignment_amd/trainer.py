@@ -251,10 +251,9 @@ class PreferenceGuidedTrainer:
             # save and hangs the other ranks in the next collective)
             should_stop = self._check_early_stopping(val_loss, sc)
             improved = val_loss < self.best_val_loss
-            if self.is_main_process:
-                self._save_checkpoint(epoch, opt, val_loss, stage, improved)
+            self._save_checkpoint(epoch, opt, opt, val_loss, stage)      # rank 0 writes (and updates best_val_loss)
             if improved:
-                self.best_val_loss = val_loss
+                self.best_val_loss = val_loss                            # ... every other rank follows
             if should_stop:
                 self.logger.info(f"Early stopping triggered at epoch {epoch}")
                 break
@@ -262,11 +261,19 @@ class PreferenceGuidedTrainer:
         return metrics
 
     def train(self) -> Dict[str, Any]:
-        out = {"stage1": self.train_stage1()}
-        if self.train_loader_stage2 is not None:
+        """Reference ``train`` (trainer.py:855-884): both stages, then the same result dict.  As in the reference
+        ``best_val_loss`` / ``patience_counter`` carry over from Stage 1 into Stage 2 (a Stage-2 checkpoint only counts as
+        "best" below the best Stage-1 loss); ``mi355x.reset_best_val_between_stages: true`` starts Stage 2 afresh."""
+        stage1_metrics = self.train_stage1()
+        if bool(self.config.get("mi355x.reset_best_val_between_stages", False)):
             self.best_val_loss, self.patience_counter = float("inf"), 0
-            out["stage2"] = self.train_stage2()
-        return out
+        stage2_metrics = self.train_stage2()
+        results = {"stage1_metrics": stage1_metrics, "stage2_metrics": stage2_metrics,
+                   "best_val_loss": self.best_val_loss, "total_steps": self.global_step}
+        if self.is_main_process:
+            self._log_metrics({"final_best_val_loss": self.best_val_loss, "total_training_steps": self.global_step})
+        self.logger.info("Training completed successfully")
+        return results
 
     # ------------------------------------------------------------------ bookkeeping
     def _log_metrics(self, m: Dict[str, Any]) -> None:
@@ -282,22 +289,41 @@ class PreferenceGuidedTrainer:
         self.patience_counter += 1
         return self.patience_counter >= patience
 
-    def _save_checkpoint(self, epoch: int, opt: FusedOptimizer, val_loss: float, stage: int, improved: bool) -> None:
-        """Same dict layout and file names as reference trainer.py:770-813 (key names of ``model_state_dict``
-        are the reference's, including the duplicated ViT and the tied lm_head).  ``mi355x_state`` is extra: what a
-        bit-faithful resume needs beyond the reference's keys (the reference's consumers ignore unknown keys)."""
+    def _save_checkpoint(self, epoch: int, optimizer, scheduler, val_loss: float, stage: int) -> None:
+        """Reference ``_save_checkpoint`` (trainer.py:770-813): same signature, dict layout and file names (the key names of
+        ``model_state_dict`` are the reference's, including the duplicated ViT and the tied lm_head); rank 0 only; a
+        ``val_loss`` below ``best_val_loss`` updates it and also writes ``best_model_stage{stage}.pt``.  The fused optimiser
+        is its own scheduler.  ``mi355x_state`` is extra: what a bit-faithful resume needs beyond the reference's keys (the
+        reference's consumers ignore unknown keys)."""
+        if not self.is_main_process:
+            return
+
+        def cpu(x):
+            if isinstance(x, torch.Tensor):
+                return x.detach().cpu()
+            if isinstance(x, dict):
+                return {k: cpu(v) for k, v in x.items()}
+            if isinstance(x, (list, tuple)):
+                return type(x)(cpu(v) for v in x)
+            return x
+
+        sched = ({"sched_step": scheduler.state()["sched_step"]} if isinstance(scheduler, FusedOptimizer)
+                 else (scheduler.state_dict() if scheduler is not None else {}))
         ck = {"epoch": epoch, "stage": stage, "global_step": self.global_step,
               "model_state_dict": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-              "optimizer_state_dict": {k: ([t.cpu() for t in v] if isinstance(v, list) else v.cpu())
-                                       for k, v in opt.state_dict().items()},
-              "scheduler_state_dict": {"sched_step": opt.state()["sched_step"]},
+              "optimizer_state_dict": cpu(optimizer.state_dict()), "scheduler_state_dict": cpu(sched),
               "val_loss": val_loss, "config": self.config.config,
               "mi355x_state": {"dropout_step": int(getattr(self, "_plan", DropoutPlan()).step),
                                "best_val_loss": min(self.best_val_loss, val_loss),
                                "patience_counter": self.patience_counter}}
-        torch.save(ck, self.checkpoint_dir / f"checkpoint_stage{stage}_epoch{epoch}.pt")
-        if improved:
+        self.checkpoint_dir.mkdir(parents=True, exist_ok=True)
+        path = self.checkpoint_dir / f"checkpoint_stage{stage}_epoch{epoch}.pt"
+        torch.save(ck, path)
+        if val_loss < self.best_val_loss:
+            self.best_val_loss = val_loss
             torch.save(ck, self.checkpoint_dir / f"best_model_stage{stage}.pt")
+            self.logger.info(f"Saved best model with val_loss: {val_loss:.4f}")
+        self.logger.info(f"Saved checkpoint: {path}")
 
     def load_checkpoint(self, path: str) -> None:
         """Reference trainer.py:836-853 (model + epoch / global_step / stage / best_val_loss) plus what it forgets:

@@ -247,3 +247,83 @@ def test_dpo_preference_loss_backward_reaches_all_four_inputs():
     assert abs(float(loss) - float(ref)) <= 1e-5 and abs(metrics["dpo_loss"] - float(ref)) <= 1e-5
     for d, c in zip(dev, cpu):
         assert torch.allclose(d.grad.cpu(), c.grad, atol=1e-6)
+
+
+# ------------------------------------------------------------------ TestPreferenceGuidedTrainer (test_training.py:62-284)
+@pytest.fixture()
+def trainer(tmp_path):
+    import os
+    from torch.utils.data import DataLoader
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.config import Config
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    from pgca_amd.trainer import PreferenceGuidedTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    arch = tiny_arch()
+    g = torch.Generator().manual_seed(11)
+
+    def item(pairs):        # the reference's dummy datasets (test_training.py:20-59): random image, ids, all-ones masks
+        d = {"image": torch.randn(3, arch.vit.image, arch.vit.image, generator=g)}
+        if pairs:
+            for k in ("preferred", "rejected"):
+                d[k + "_ids"] = torch.randint(0, arch.gpt.base_vocab, (16,), generator=g)
+                d[k + "_mask"] = torch.ones(16, dtype=torch.long)
+            d["preference_score"] = torch.rand(1, generator=g)[0]
+        else:
+            d["caption_ids"] = torch.randint(0, arch.gpt.base_vocab, (16,), generator=g)
+            d["caption_mask"] = torch.ones(16, dtype=torch.long)
+        return d
+
+    mk = lambda pairs, n: DataLoader([item(pairs) for _ in range(n)], batch_size=2, shuffle=False)  # noqa: E731
+    cfg = Config(os.path.join(root, "configs", "default.yaml"))
+    cfg.set("paths.output_dir", str(tmp_path))
+    cfg.set("training.stage1.num_epochs", 1)
+    cfg.set("training.stage2.num_epochs", 1)
+    cfg.set("training.stage1.gradient_accumulation_steps", 1)
+    cfg.set("training.stage2.gradient_accumulation_steps", 1)
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=arch, seed=4, device=DEV)
+    return PreferenceGuidedTrainer(model=model, config=cfg, train_loader_stage1=mk(False, 8), val_loader_stage1=mk(False, 4),
+                                   train_loader_stage2=mk(True, 8), val_loader_stage2=mk(True, 4))
+
+
+def test_trainer_init_checkpoint_roundtrip_and_early_stopping(trainer):
+    from unittest.mock import MagicMock
+    tr = trainer
+    assert tr.model is not None and tr.config is not None
+    assert all(getattr(tr, a) is not None for a in ("train_loader_stage1", "val_loader_stage1", "train_loader_stage2",
+                                                    "val_loader_stage2"))
+    assert tr.current_stage == 1 and tr.global_step == 0 and tr.epoch == 0
+    # test_save_checkpoint (test_training.py:157-181): any object with state_dict() is accepted, as in the reference
+    opt, sch = MagicMock(), MagicMock()
+    opt.state_dict.return_value = {"lr": 1e-4}
+    sch.state_dict.return_value = {"step": 100}
+    tr._save_checkpoint(epoch=1, optimizer=opt, scheduler=sch, val_loss=0.5, stage=1)
+    assert tr.checkpoint_dir.exists() and len(list(tr.checkpoint_dir.glob("checkpoint_*.pt"))) > 0
+    assert tr.best_val_loss == 0.5 and (tr.checkpoint_dir / "best_model_stage1.pt").exists()
+    # test_load_checkpoint (:183-205): a checkpoint holding only the reference's mandatory keys
+    path = tr.checkpoint_dir / "test_checkpoint.pt"
+    torch.save({"epoch": 5, "stage": 2, "global_step": 1000, "model_state_dict": tr.model.state_dict(), "val_loss": 0.3,
+                "config": tr.config.config}, path)
+    tr.load_checkpoint(str(path))
+    assert tr.epoch == 5 and tr.current_stage == 2 and tr.global_step == 1000 and tr.best_val_loss == 0.3
+    # _check_early_stopping (trainer.py:815-834): counts epochs that do not beat best_val_loss, which only
+    # _save_checkpoint moves
+    tr.best_val_loss, tr.patience_counter = 0.5, 0
+    cfg = {"early_stopping_patience": 3}
+    assert not tr._check_early_stopping(0.4, cfg) and tr.patience_counter == 0
+    assert not tr._check_early_stopping(0.6, cfg) and tr.patience_counter == 1
+    assert not tr._check_early_stopping(0.7, cfg) and tr.patience_counter == 2
+    assert tr._check_early_stopping(0.8, cfg) and tr.patience_counter == 3
+
+
+def test_trainer_stages_and_full_pipeline_result_keys(trainer):
+    tr = trainer
+    m1 = tr.train_stage1()
+    assert isinstance(m1, dict) and {"train_loss", "val_loss"} <= set(m1) and len(m1["train_loss"]) == 1
+    m2 = tr.train_stage2()
+    assert isinstance(m2, dict) and {"train_loss", "val_loss"} <= set(m2) and len(m2["train_loss"]) == 1
+    res = tr.train()
+    assert isinstance(res, dict) and {"stage1_metrics", "stage2_metrics", "best_val_loss", "total_steps"} <= set(res)
+    assert res["total_steps"] == tr.global_step
+    tr.train_loader_stage2 = None                 # trainer.py:375-377: no Stage-2 loader -> skipped, empty metrics
+    assert tr.train_stage2() == {}

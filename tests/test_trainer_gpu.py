@@ -84,7 +84,9 @@ def test_trainer_two_stages_tiny(tmp_path):
     tr = PreferenceGuidedTrainer(model, cfg, mk(False, 1, 20), mk(False, 2, 8), mk(True, 3, 20), mk(True, 4, 8))
     assert tr.accum == 2
     out = tr.train()
-    s1, s2 = out["stage1"], out["stage2"]
+    assert set(out) == {"stage1_metrics", "stage2_metrics", "best_val_loss", "total_steps"}    # reference trainer.py:869-874
+    assert out["total_steps"] == tr.global_step and out["best_val_loss"] == tr.best_val_loss
+    s1, s2 = out["stage1_metrics"], out["stage2_metrics"]
     assert len(s1["train_loss"]) == 2 and len(s2["train_loss"]) == 2
     assert all(np.isfinite(s1["train_loss"] + s1["val_loss"] + s2["train_loss"] + s2["val_loss"]))
     assert s1["train_loss"][1] < s1["train_loss"][0]            # same 20 samples twice: NT-Xent must fall
