@@ -179,7 +179,8 @@ class OverlappedTrunkReducer:
         self.hi = trunk.layer_ranges[-1][1]
 
     def arm(self) -> None:
-        self.trunk.grad_hook = self._on_layer if self.dp.world > 1 else None
+        # a frozen trunk (no gradient buffer) has nothing to reduce: only the other segments travel in finish()
+        self.trunk.grad_hook = self._on_layer if (self.dp.world > 1 and self.seg.grad is not None) else None
 
     def disarm(self) -> None:
         self.trunk.grad_hook = None
@@ -192,10 +193,11 @@ class OverlappedTrunkReducer:
 
     def finish(self, other_segments=()) -> None:
         if self.dp.world > 1:
-            if self.trunk.grad_hook is None:  # not armed: reduce the layers too
-                self.dp.all_reduce_range(self.seg.grad, self.lo, self.hi)
-            self.dp.all_reduce_range(self.seg.grad, 0, self.lo)
-            self.dp.all_reduce_range(self.seg.grad, self.hi, self.seg.numel)
+            if self.seg.grad is not None:
+                if self.trunk.grad_hook is None:  # not armed: reduce the layers too
+                    self.dp.all_reduce_range(self.seg.grad, self.lo, self.hi)
+                self.dp.all_reduce_range(self.seg.grad, 0, self.lo)
+                self.dp.all_reduce_range(self.seg.grad, self.hi, self.seg.numel)
             for s in other_segments:
                 self.dp.all_reduce_range(s.grad, 0, s.numel)
             self.dp.join()

@@ -896,7 +896,7 @@ class TextTowerEngine:
         H, M = a.hidden, B * S
         h0 = self._buf("h0", (M, H), F32)
         hip.embed_fwd(ids, B, S, H, self.wte.w, self.wpe.w, h0, drop_e=drop(0, KIND_EMBD) if drop is not None else None)
-        hL = self.trunk.forward(h0, mask, B, S, save, drop)
+        hL = self.trunk.forward(h0, mask, B, S, save and self.seg.grad is not None, drop)
         feats = self._buf("feats", (M, H), F32)
         mf, rf = self._buf("mf", (M,), F32), self._buf("rf", (M,), F32)
         hip.layernorm_fwd(hL, M, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_f32=feats, mean=mf, rstd=rf)
@@ -913,6 +913,9 @@ class TextTowerEngine:
         s, a, ws = self.saved, self.arch.gpt, self.ws
         B, S, H = s["B"], s["S"], a.hidden
         M = B * S
+        if self.seg.grad is None:      # freeze_text_backbone=True (reference model.py:354-368): only the head trains
+            self.head.backward(demb, need_dx=False)
+            return
         dpooled = self.head.backward(demb, need_dx=True)
         dfeats = self._buf("dfeats", (M, H), F32)
         hip.masked_mean_bwd(dpooled, s["mask"], B, S, H, dfeats)

@@ -140,6 +140,8 @@ class TextEncoder:
             dev = self._o.device
             ids = input_ids.to(dev, I64).contiguous()
             mask = (attention_mask != 0).to(I32).to(dev).contiguous()
+            if return_hidden_states and self.freeze_backbone:
+                raise NotImplementedError("hidden_states of a frozen text tower are not kept (its layers run in place)")
             feats, pooled, emb = self.engine.forward(ids, mask, save=bool(return_hidden_states))
         except Exception as e:  # reference model.py:458-460
             raise RuntimeError(f"Text encoding failed: {e}") from e

@@ -96,9 +96,6 @@ class PreferenceGuidedTrainer:
         sc = self.config.get(f"training.stage{stage}")
         # the CLIP tower joins when it was left trainable (reference AdamW(model.parameters()), trainer.py:275-281)
         names = ("vit", "vision_head", "text_tower", "text_head") if stage == 1 else ("vit", "vision_head", "decoder")
-        if stage == 1 and not self.model.store.segments["text_tower"].trainable:
-            raise NotImplementedError("Stage 1 with freeze_text_backbone=True is not supported on the MI355X path: the "
-                                      "text tower's backward always produces its weight gradients")
         segs = [self.model.store.segments[n] for n in names if self.model.store.segments[n].trainable]
         opt = FusedOptimizer(segs, lr=sc["learning_rate"], weight_decay=sc.get("weight_decay", 0.01),
                              betas=(0.9, 0.999), eps=1e-8, max_grad_norm=sc.get("max_grad_norm"),

@@ -177,12 +177,46 @@ def test_resume_restores_optimizer_scheduler_and_continues(tmp_path):
         m2.load_state_dict(bad)
 
 
-def test_stage1_rejects_frozen_text_tower(tmp_path):
+def test_stage1_with_frozen_text_tower_trains_the_heads_only(tmp_path):
+    """``freeze_text_backbone=True`` (reference model.py:354-368): Stage 1 leaves the GPT-2 tower untouched and trains the
+    two projection heads; their gradients equal the oracle's with the towers treated as constants."""
+    from oracle import restatement as R
     from pgca_amd.arch import tiny_arch
     from pgca_amd.model import PreferenceGuidedCaptioningModel
+    from pgca_amd.steps import ContrastiveStep
     from pgca_amd.trainer import PreferenceGuidedTrainer
-    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, freeze_text_backbone=True, arch=tiny_arch(),
+    arch = tiny_arch()
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, freeze_text_backbone=True, arch=arch, dropout=0.0,
                                             seed=1, device=DEV)
-    tr = PreferenceGuidedTrainer(model, _config(tmp_path, 1, 1, 1e-3, False), ListLoader([]), ListLoader([]))
-    with pytest.raises(NotImplementedError, match="freeze_text_backbone"):
-        tr.train_stage1()
+    assert model.store.segments["text_tower"].grad is None
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(4, 3, arch.vit.image, arch.vit.image, generator=g)
+    ids = torch.randint(0, arch.gpt.base_vocab, (4, 16), generator=g)
+    mask = (torch.arange(16)[None] < torch.tensor([16, 7, 11, 3])[:, None]).long()
+    step = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                           model.text_encoder.engine, temperature=0.5)
+    p = ContrastiveStep.prepare({"image": img, "caption_ids": ids, "caption_mask": mask}, model.device)
+    for s_ in model.store.trainable_segments():
+        s_.grad.zero_()
+    loss = float(step.loss_and_grads(p["image"], p["ids"], p["mask"]))
+    sd = {k: v.detach().cpu().clone().requires_grad_(".projection." in k)
+          for k, v in model.store.state_dict(aliases=False).items()}
+    ie = R.vision_encoder_forward(sd, img, arch.vit.heads, arch.vit.patch)["embeddings"]
+    te = R.text_encoder_forward(sd, ids, mask, arch.gpt.heads)["embeddings"]
+    n = torch.nn.functional.normalize
+    ref = R.nt_xent(n(ie, dim=-1), n(te, dim=-1), 0.5)
+    ref.backward()
+    assert abs(loss - float(ref)) <= 5e-3
+    for name in ("text_encoder.projection.0.weight", "text_encoder.projection.3.weight", "text_encoder.projection.4.weight",
+                 "vision_encoder.projection.0.weight"):
+        a, b = model.store.g(name).double().flatten().cpu(), sd[name].grad.double().flatten()
+        assert float((a @ b) / (a.norm() * b.norm())) >= 0.99, name
+    # the trainer runs Stage 1 on such a model and moves the heads only
+    before = {k: s_.fp32.clone() for k, s_ in model.store.segments.items()}
+    batches = [{"image": img, "caption_ids": ids, "caption_mask": mask}] * 2
+    tr = PreferenceGuidedTrainer(model, _config(tmp_path, 1, 1, 1e-3, False), ListLoader(batches), ListLoader(batches))
+    tr.train_stage1()
+    assert torch.equal(model.store.segments["text_tower"].fp32, before["text_tower"])
+    assert torch.equal(model.store.segments["vit"].fp32, before["vit"])
+    assert not torch.equal(model.store.segments["text_head"].fp32, before["text_head"])
+    assert not torch.equal(model.store.segments["vision_head"].fp32, before["vision_head"])
