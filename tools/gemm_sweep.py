@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--hidden", type=int, default=1024)
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--library", action="store_true",
+                    help="add a column: torch.matmul (hipBLASLt) on the same operands, PLAIN product without the epilogue")
     args = ap.parse_args()
     vals = [int(v) for v in args.values.split(",")]
     dev = torch.device("cuda:0")
@@ -47,7 +49,20 @@ def main():
         "dgelu NT dgrad": (lambda: hip.gemm(x, wpr, M, 4 * H, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=o4b, out_bf16=o4), 2.0 * M * 4 * H * H),
         "plain NT dgrad K=4H": (lambda: hip.gemm(x4, wfc, M, H, 4 * H, hip.NT, out_bf16=o3[:, :H].contiguous()), 2.0 * M * 4 * H * H),
     }
+    lib = {}
+    if args.library:   # the library's plain GEMM (bf16 out) on the same shapes: what the fused kernels are held against
+        wt = {"NT_fc": wpr.t().contiguous(), "NT_4h": wfc.t().contiguous()}
+        lib = {
+            "qkv  (bias->bf16)": lambda: torch.matmul(x, wqkv),
+            "proj (res f32+drop)": lambda: torch.matmul(x, wo),
+            "fc   (gelu, 2 outs)": lambda: torch.matmul(x, wfc),
+            "fc   (gelu, 1 out)": lambda: torch.matmul(x, wfc),
+            "fc2  (res f32+drop)": lambda: torch.matmul(x4, wpr),
+            "dgelu NT dgrad": lambda: torch.matmul(x, wt["NT_fc"]),
+            "plain NT dgrad K=4H": lambda: torch.matmul(x4, wt["NT_4h"]),
+        }
     times = {(n, v): [] for n in shapes for v in vals}
+    ltimes = {n: [] for n in lib}
     for rnd in range(args.rounds + 1):
         for v in vals:
             hip.set_option(args.option, v)
@@ -62,11 +77,26 @@ def main():
                 torch.cuda.synchronize()
                 if rnd:
                     times[n, v].append(e0.elapsed_time(e1) * 1e3 / args.iters)
-    print(f"{args.option:>22s} " + " ".join(f"{v:>14d}" for v in vals))
+    for n, fn in lib.items():
+        for rnd in range(args.rounds + 1):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd:
+                ltimes[n].append(e0.elapsed_time(e1) * 1e3 / args.iters)
+    print(f"{args.option:>22s} " + " ".join(f"{v:>14d}" for v in vals) + ("   hipBLASLt plain" if lib else ""))
     for n, (_, fl) in shapes.items():
         cells = []
         for v in vals:
             t = sorted(times[n, v])[len(times[n, v]) // 2]
+            cells.append(f"{t:7.1f}us {fl / t / 1e6:5.0f}T")
+        if lib:
+            t = sorted(ltimes[n])[len(ltimes[n]) // 2]
             cells.append(f"{t:7.1f}us {fl / t / 1e6:5.0f}T")
         print(f"{n:>22s} " + " ".join(cells), flush=True)
 
