@@ -151,22 +151,30 @@ __global__ void rowstats_combine_kernel(const float* __restrict__ smax, const fl
 // SOURCE address (same involution as the fragment readers).  Edges: M/N by clamping the source
 // row/column (clamped rows only feed outputs the epilogue masks), K must be a multiple of 64.
 // ================================================================================================
-template <int LA, int LB>
+// RAW: bid_in is already the tile (tm * ntn + tn) - the grouped launch places its tiles itself.
+template <int LA, int LB, bool RAW = false>
 __device__ __forceinline__ void gemm256_body(const pgca_gemm_args& a, int ntm, int ntn, int nk_per_split, int bid_in,
                                              int ksplit, unsigned char* smem2) {  // smem2: [2 stages][A | B][32 KiB]
   const int nwg = ntm * ntn;
   int bid = bid_in;
-  {
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  int tm, tn;
+  if (RAW) {
+    tm = bid / ntn;
+    tn = bid - tm * ntn;
+  } else {
+    {
+      const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GROUP_M = 8;
+    const int per_group = GROUP_M * ntn;
+    const int group = bid / per_group;
+    const int first_m = group * GROUP_M;
+    const int gsize = min(GROUP_M, ntm - first_m);
+    const int in_group = bid - group * per_group;
+    tm = first_m + in_group % gsize;
+    tn = in_group / gsize;
   }
-  constexpr int GROUP_M = 8;
-  const int per_group = GROUP_M * ntn;
-  const int group = bid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsize = min(GROUP_M, ntm - first_m);
-  const int in_group = bid - group * per_group;
-  const int tm = first_m + in_group % gsize, tn = in_group / gsize;
   const int m0 = tm * BM2, n0 = tn * BN2;
 
   const int t = threadIdx.x;
@@ -265,7 +273,16 @@ struct pgca_group_param {
 
 __global__ __launch_bounds__(512, 2) void gemm256_group_tn_kernel(const pgca_group_param gp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
-  const int b = blockIdx.x;
+  // Tile placement.  Workgroup b runs on XCD b % 8, and every XCD has its own 4 MiB L2: the tiles are laid out problem
+  // after problem with the SHORTER tile dimension running fastest, and XCD x takes a contiguous run of that order - a
+  // compact rectangle of (mostly) one problem, so the 24 tiles an XCD holds for a GPT-2-M block stream ~11 operand panels
+  // through its L2 instead of ~24 when every problem is spread over all eight XCDs.
+  int b;
+  {
+    const int total = gp.start[4];
+    const int xcd = blockIdx.x & 7, q = total >> 3, r = total & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+  }
   int p = 0;
   if (b >= gp.start[1]) p = 1;
   if (b >= gp.start[2]) p = 2;
@@ -291,7 +308,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_group_tn_kernel(const pgca_gro
   const int ntm = p == 0 ? gp.ntm[0] : p == 1 ? gp.ntm[1] : p == 2 ? gp.ntm[2] : gp.ntm[3];
   const int ntn = p == 0 ? gp.ntn[0] : p == 1 ? gp.ntn[1] : p == 2 ? gp.ntn[2] : gp.ntn[3];
   const int st = p == 0 ? gp.start[0] : p == 1 ? gp.start[1] : p == 2 ? gp.start[2] : gp.start[3];
-  gemm256_body<1, 1>(a, ntm, ntn, a.K / BK, b - st, 0, smem2);
+  const int l = b - st;
+  int tm, tn;
+  if (ntm <= ntn) {
+    tn = l / ntm;
+    tm = l - tn * ntm;
+  } else {
+    tm = l / ntn;
+    tn = l - tm * ntn;
+  }
+  gemm256_body<1, 1, true>(a, ntm, ntn, a.K / BK, tm * ntn + tn, 0, smem2);
 }
 
 constexpr size_t GEMM256_LDS = 4 * TILE2_BYTES;  // 128 KiB
