@@ -205,7 +205,8 @@ class GptTrunk:
     """GPT-2 blocks + ln_f on an f32 residual stream (HF GPT2Block, modeling_gpt2.py:246-310).
 
     Weights are Conv1D ``[in, out]``: forward is an NN GEMM, dgrad NT, wgrad TN - all from the
-    one bf16 mirror.  Dropout sites are identity (p = 0 / eval semantics).
+    one bf16 mirror.  The attn / resid dropout sites take the triple ``drop(layer, kind)`` yields (train mode) and are
+    replayed in the backward; without ``drop`` they are the identity (eval semantics).
     """
 
     def __init__(self, store: ParamStore, prefix: str, arch: GptArch, ws: Workspace, tag: str):
@@ -380,7 +381,8 @@ class GptTrunk:
 
 # ------------------------------------------------------------------------------------------ projection heads
 class ProjHead:
-    """Linear -> ReLU -> Dropout(identity) -> Linear -> LayerNorm (reference model.py:136-142,338-344)."""
+    """Linear -> ReLU -> Dropout (fused into the first GEMM's epilogue when ``drop`` is given) -> Linear -> LayerNorm
+    (reference model.py:136-142,338-344)."""
 
     def __init__(self, store: ParamStore, prefix: str, in_dim: int, proj: int, ws: Workspace, tag: str):
         seg = store.seg_of(prefix + ".0.weight")
