@@ -36,7 +36,7 @@ typedef enum pgca_status {
   PGCA_ERR_LAUNCH = -2   /* hipLaunch failed; see pgca_last_error() */
 } pgca_status;
 
-#define PGCA_ABI_VERSION 200 /* bumped whenever a signature or struct layout below changes */
+#define PGCA_ABI_VERSION 201 /* bumped whenever a signature or struct layout below changes */
 int pgca_version(void);        /* == PGCA_ABI_VERSION of the header the library was built from */
 int pgca_sizeof_gemm_args(void); /* sizeof(pgca_gemm_args) as compiled: bindings compare it with their own layout */
 const char* pgca_last_error(void);
@@ -101,6 +101,11 @@ typedef struct pgca_gemm_args {
   uint32_t drop_seed;
   uint32_t drop_threshold;
   float drop_scale;
+  /* Optional, PGCA_EPI_DGELU_NEW only: f32 [ceil(M/64), ld_colsum] - row b receives the column sums of the rows
+   * 64b .. 64b+63 of the result (before its bf16 rounding); summed over b (pgca_colsum_finish) they are the bias gradient
+   * of the layer whose pre-activation gradient this GEMM produces, without a second pass over the M x N result. */
+  float* colsum_part;
+  int32_t ld_colsum;
 } pgca_gemm_args;
 
 int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);

@@ -467,6 +467,10 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       return PGCA_ERR_INVALID;
     }
   }
+  if (a.colsum_part && (a.epilogue != PGCA_EPI_DGELU_NEW || a.ld_colsum < a.N || a.accumulate == 2)) {
+    set_error("pgca_gemm_bf16: colsum_part needs the DGELU_NEW epilogue, ld_colsum >= N and no split-K");
+    return PGCA_ERR_INVALID;
+  }
   const int ncols = a.epilogue == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
   hipStream_t s = (hipStream_t)stream;
   {

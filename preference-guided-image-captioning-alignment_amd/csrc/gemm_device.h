@@ -171,6 +171,25 @@ __device__ __forceinline__ void epilogue_rowstats(const pgca_gemm_args& a, f32x4
 
 __device__ __forceinline__ bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
+// Column sums of one 64 x 64 block (pgca_gemm_args::colsum_part): every lane holds the sums of its 8 columns over the
+// rows it handled; the eight lanes that share those columns (lane bits 3..5 = row within the slab) are folded with three
+// DPP-free shuffles and lane-row 0 writes row `brow` of the partial matrix.
+__device__ __forceinline__ void colsum_flush(const pgca_gemm_args& a, float (&cs)[8], int brow, int col, int ncols,
+                                             int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    cs[j] += __shfl_xor(cs[j], 8);
+    cs[j] += __shfl_xor(cs[j], 16);
+    cs[j] += __shfl_xor(cs[j], 32);
+  }
+  if ((lane >> 3) == 0 && brow * 64 < a.M) {
+    float* p = a.colsum_part + (size_t)brow * a.ld_colsum + col;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (col + j < ncols) p[j] = cs[j];
+  }
+}
+
 // Everything that happens to 8 consecutive output columns of one row.  `nv` = number of valid columns (1..8);
 // the 16-byte vector paths are taken when nv == 8 and the row start is 16-B aligned, else element-wise.
 template <int EPI>
@@ -332,6 +351,12 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
     b0 = *reinterpret_cast<const float4*>(a.bias + col);
     b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
   }
+  constexpr bool CSUM = EPI == PGCA_EPI_DGELU_NEW;
+  float cs[8];
+  if constexpr (CSUM) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+  }
   float4 pre[PF != PF_NONE ? 8 : 1][2];
   bf16x8 ax[AUXIN ? 8 : 1];
   float lse[EPI == PGCA_EPI_DLOGITS ? 8 : 1], rsc[EPI == PGCA_EPI_DLOGITS ? 8 : 1];
@@ -415,6 +440,10 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] *= m0[j]; v[j + 4] *= m1[j]; }
       }
+      if constexpr (CSUM) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] += v[j];
+      }
       if (PF == PF_RES) {
         const float4 p0 = pre[PF != PF_NONE ? i8 : 0][0], p1 = pre[PF != PF_NONE ? i8 : 0][1];
         v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
@@ -436,6 +465,9 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.out_bf16) + (size_t)row * a.ld_out_bf16 + col) = tq;
       }
     }
+  }
+  if constexpr (CSUM) {
+    if (a.colsum_part) colsum_flush(a, cs, mb >> 6, col, a.N, lane);
   }
 }
 
@@ -473,6 +505,8 @@ __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&
   }
   float* cbuf = reinterpret_cast<float*>(smem) + wave * CB_WAVE_FLOATS;
   const int ncols = EPI == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
+  constexpr bool CSUM = EPI == PGCA_EPI_DGELU_NEW;
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     cb_write(cbuf, acc, mi, lane);
@@ -504,9 +538,16 @@ __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&
           }
           const int nv = ncols - col < 8 ? ncols - col : 8;
           finish8<EPI>(a, row, col, v, nv, lse, rscale, tgt);
+          if constexpr (CSUM) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[j] += j < nv ? v[j] : 0.f;
+          }
         }
       }
     }
+  }
+  if constexpr (CSUM) {
+    if (a.colsum_part) colsum_flush(a, cs, (m0 + wm * 64) >> 6, n0 + wn * 64 + (lane & 7) * 8, ncols, lane);
   }
 }
 

@@ -330,12 +330,17 @@ class GptTrunk:
             settle(li + 2)   # that launch read dpre / dqkv of this parity
             # ---- MLP: h_out = hm + c_proj(gelu(c_fc(ln2(hm))))
             dpre = self._buf("dpre" + par, (M, I), BF16)
-            hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=s["pre"], out_bf16=dpre)
+            # the same GEMM leaves the column sums of dpre per 64-row block: mlp.c_fc's bias gradient without a second
+            # pass over the M x 4H matrix
+            nbr = (M + 63) // 64
+            dpre_cs = self._buf("dpre_colsum", (nbr, I), F32)
+            hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=s["pre"], out_bf16=dpre,
+                     colsum_part=dpre_cs)
+            hip.colsum_finish(dpre_cs, nbr, I, P["bfc"].g, accumulate=True)
             wgrads = [(s["act"], g_bf, I, H, M, P["wpr"].g)]   # the layer's four weight gradients go out together
             dln = self._buf("dln", (M, H), BF16)
             hip.gemm(dpre, P["wfc"].b, M, H, I, hip.NT, out_bf16=dln)
             wgrads.append((s["ln2"], dpre, H, I, M, P["wfc"].g))
-            _bias_grad(ws, M, I, I, P["bfc"].g, x_bf16=dpre)
             g2 = self._buf("g_b" if (li & 1) else "g_a", (M, H), F32)
             g2_bf = self._buf("gbf_b" if (li & 1) else "gbf_a", (M, H), BF16)
             hip.layernorm_bwd(s["hm"], M, H, P["ln2w"].w, s["m2"], s["r2"], g2, dy_bf16=dln, add_to=g, dx_bf16=g2_bf,

@@ -39,6 +39,7 @@ class GemmArgs(C.Structure):
         ("target_val", _vp), ("row_lse", _vp), ("row_scale", _vp),
         ("out_cols", _i32),
         ("drop_seed", C.c_uint32), ("drop_threshold", C.c_uint32), ("drop_scale", _f32),
+        ("colsum_part", _vp), ("ld_colsum", _i32),
     ]
 
 
@@ -92,7 +93,7 @@ _SIGS = {
     "pgca_gather_rows_bf16": [_vp, _vp, _i32, _i32, _vp, _vp],
 }
 EXPORTS = ["pgca_version", "pgca_last_error", "pgca_sizeof_gemm_args"] + list(_SIGS)
-ABI_VERSION = 200  # include/pgca_hip.h PGCA_ABI_VERSION
+ABI_VERSION = 201  # include/pgca_hip.h PGCA_ABI_VERSION
 
 _lib = None
 
@@ -145,7 +146,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
          aux_out: torch.Tensor = None, aux_in: torch.Tensor = None, ld_aux: int = None,
          targets: torch.Tensor = None, stat_max: torch.Tensor = None, stat_sum: torch.Tensor = None, stat_ld: int = 0,
          target_val: torch.Tensor = None, row_lse: torch.Tensor = None, row_scale: torch.Tensor = None,
-         out_cols: int = 0, drop=None) -> None:
+         out_cols: int = 0, drop=None, colsum_part: torch.Tensor = None) -> None:
     a = GemmArgs()
     a.A, a.B = A.data_ptr(), B.data_ptr()
     a.M, a.N, a.K = M, N, K
@@ -163,6 +164,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
     a.out_cols = out_cols
     if drop is not None:
         a.drop_seed, a.drop_threshold, a.drop_scale = drop
+    if colsum_part is not None:
+        a.colsum_part, a.ld_colsum = colsum_part.data_ptr(), colsum_part.shape[1]
     probe = gemm_probe
     if probe is not None and probe.want(layout, epilogue, load().pgca_gemm_plan(C.byref(a))):
         # HIP events on the launch stream bracket this one kernel (bench.py roofline measurement)

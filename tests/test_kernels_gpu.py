@@ -683,3 +683,33 @@ def test_grouped_weight_gradient_launch(hip):
         hip.gemm_wgrad_group(probs)
         for (x, dy, M, N, K, gout), ref in zip(probs, refs):
             close(gout, ref, 3e-4, f"grouped wgrad {M}x{N} K={K}")
+
+
+@pytest.mark.parametrize("shape", [(512, 512, 256), (300, 200, 128), (1024, 4096, 64), (64, 72, 64), (130, 520, 192)])
+def test_dgelu_gemm_leaves_bias_gradient_partials(hip, tile, shape):
+    """``colsum_part`` (DGELU_NEW epilogue): row b of the partial matrix holds the column sums of rows 64b..64b+63 of the
+    result; summed over b they are colsum(dpre) = the bias gradient of mlp.c_fc (HF modeling_gpt2.py:229-243 under
+    trainer.py:494,606 loss.backward()) - fast path, edge blocks in M and in N, both tile sizes."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(dev()).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.5).to(dev()).bfloat16()          # NT: out = a @ w^t
+    pre = torch.randn(M, N, generator=g).to(dev()).bfloat16()
+    nbr = (M + 63) // 64
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    part = torch.full((nbr, N), float("nan"), device=dev())
+    hip.gemm(a, w, M, N, K, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=pre, out_bf16=out, colsum_part=part)
+    x = pre.float()
+    k2 = 2.0 * 0.7978845608028654
+    s = torch.sigmoid(k2 * x * (1 + 0.044715 * x * x))
+    want = (a.float() @ w.float().t()) * (s + x * s * (1 - s) * k2 * (1 + 3 * 0.044715 * x * x))
+    assert torch.isfinite(part).all()                                           # every (block row, column) was written
+    for b in range(nbr):
+        ref = want[64 * b:64 * b + 64].double().sum(0)
+        close(part[b].double(), ref, 2e-3, f"block row {b}")
+    bias_grad = torch.full((N,), 1.0, device=dev())
+    hip.colsum_finish(part, nbr, N, bias_grad, accumulate=True)
+    close(bias_grad.double() - 1.0, want.double().sum(0), 2e-3, "bias gradient")
+    close(out.float(), want, 2e-2, "dpre itself")
+    with pytest.raises(RuntimeError, match="colsum_part"):
+        hip.gemm(a, w, M, N, K, hip.NT, out_bf16=out, colsum_part=part)
