@@ -367,7 +367,7 @@ class GptTrunk:
                 done[li] = ev
             else:
                 hip.gemm_wgrad_group(wgrads)
-            # (moving these HBM-bound column sums to the side stream as well measured neutral: they stay here)
+            # (moving this HBM-bound column sum to the side stream as well measured neutral: it stays here)
             _bias_grad(ws, M, 3 * H, 3 * H, P["bqkv"].g, x_bf16=dqkv)
             g3 = self._buf("g_c" if (li & 1) else "g_d", (M, H), F32)
             g3_bf = self._buf("gbf_c" if (li & 1) else "gbf_d", (M, H), BF16)
