@@ -82,10 +82,20 @@ __global__ void seq_reduce_kernel(const float* __restrict__ tok, const int* __re
   const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nseq) return;
-  // rows of sequence q: binary search is overkill - rows are sorted by sequence; scan with stride 64
   float s = 0.f;
-  for (int r = lane; r < nrows; r += 64)
-    if (seq_of_row[r] == q) s += tok[r];
+  if (seq_count) {
+    // rows are sorted by sequence: this one's start is the sum of the counts before it (<= a few thousand integers,
+    // 64 lanes wide) - O(nseq + count) per wave instead of a scan over every row of the batch
+    int before = 0;
+    for (int i = lane; i < q; i += 64) before += seq_count[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    const int n = seq_count[q];
+    for (int r = lane; r < n; r += 64) s += tok[before + r];
+  } else {
+    for (int r = lane; r < nrows; r += 64)
+      if (seq_of_row[r] == q) s += tok[r];
+  }
   s = wave_sum(s);
   if (lane == 0) out[q] = mode ? s / (float)seq_count[q] : s;
 }
