@@ -262,7 +262,7 @@ def main():
         p = next(feeder) if feeder is not None else batches[i % nbatch]
         opt.zero_grad()
         if stage1:
-            last[0] = step.loss_and_grads(p["image"], p["ids"], p["mask"])
+            last[0] = step.loss_and_grads(p["image"], p["ids"], p["mask"], pack=p.get("pack"))
         else:
             last[0] = step.loss_and_grads(p["image"], p["seq"])
         reducer.finish(other_segments=segs[:-1])

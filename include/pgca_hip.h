@@ -36,7 +36,7 @@ typedef enum pgca_status {
   PGCA_ERR_LAUNCH = -2   /* hipLaunch failed; see pgca_last_error() */
 } pgca_status;
 
-#define PGCA_ABI_VERSION 201 /* bumped whenever a signature or struct layout below changes */
+#define PGCA_ABI_VERSION 300 /* bumped whenever a signature or struct layout below changes */
 int pgca_version(void);        /* == PGCA_ABI_VERSION of the header the library was built from */
 int pgca_sizeof_gemm_args(void); /* sizeof(pgca_gemm_args) as compiled: bindings compare it with their own layout */
 const char* pgca_last_error(void);
@@ -106,6 +106,10 @@ typedef struct pgca_gemm_args {
    * of the layer whose pre-activation gradient this GEMM produces, without a second pass over the M x N result. */
   float* colsum_part;
   int32_t ld_colsum;
+  /* Optional, packed (variable-length) token rows: drop_rows[m] is the row index the dropout hash is keyed on instead of m
+   * (the token's position b*S + t in the PADDED [B, S] layout of the reference batch), so a packed launch draws exactly the
+   * masks of the padded one.  int32 [M]; entries of padding rows may hold anything (their values are never used). */
+  const int32_t* drop_rows;
 } pgca_gemm_args;
 
 int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream);
@@ -151,12 +155,13 @@ int pgca_layernorm_fwd(const float* x, const int32_t* row_map, int32_t M, int32_
  * sums of add_to and of dx_out - the bias gradients of the two GEMMs around this LayerNorm, for free.
  * drop_add / drop_dx (HOST pointers to {seed, threshold, scale-as-float-bits}, or NULL) replay the dropout masks of
  * those two GEMM outputs: the add_to column sum uses drop_add; dx_bf16 and the dx column sum use drop_dx (dx_out
- * itself, the f32 residual-stream gradient, is never masked). */
+ * itself, the f32 residual-stream gradient, is never masked).  drop_rows (optional, int32 [rows]): the row index the two
+ * dropout hashes are keyed on (see pgca_gemm_args::drop_rows; packed token rows). */
 int pgca_layernorm_bwd_blocks(int32_t M);
 int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
                        int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
                        const float* add_to, float* dx_out, void* dx_bf16, float* part, float* part_extra,
-                       const uint32_t* drop_add, const uint32_t* drop_dx, void* stream);
+                       const uint32_t* drop_add, const uint32_t* drop_dx, const int32_t* drop_rows, void* stream);
 /* out[h] (+)= sum_b part[b, h]; nparts rows of length H. */
 int pgca_colsum_finish(const float* part, int32_t nparts, int32_t H, float* out, int32_t accumulate, void* stream);
 
@@ -173,16 +178,21 @@ int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, in
  * softmax(q k^t / 8 + mask) v with mask = causal AND key_mask[b, key] != 0 (key_mask int32 [B,S] or NULL).
  * Any S in the forward (one on-chip tile up to 128, key-tiled online softmax beyond); the backward keeps the dQ
  * accumulators of every 128-query block in registers: S <= PGCA_ATTN_MAX_S.  B <= 65535.
- * Replaces SDPA at modeling_gpt2.py:54-72,203-215 and modeling_clip.py:259-277. */
+ * Replaces SDPA at modeling_gpt2.py:54-72,203-215 and modeling_clip.py:259-277.
+ * Packed (variable-length) rows: with cu_seqlens (int32 [B+1], cu[0] = 0) sequence b occupies rows cu[b] .. cu[b+1]-1 of
+ * qkv / out / dout / dqkv and has cu[b+1]-cu[b] <= S tokens; S stays the PADDED length: key_mask, lse and the dropout index
+ * keep their [B, S] geometry, so the result of every real token equals the padded launch's.  Padding positions of the
+ * reference batch (model.py:1069-1083 zeroes their loss terms, :449-456 their pooling weight) are then never computed. */
 #define PGCA_ATTN_MAX_S 512
 int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int32_t B, int32_t S, int32_t heads,
                        int32_t causal, void* out, float* lse, uint32_t drop_seed, uint32_t drop_threshold,
-                       float drop_scale, void* stream);
+                       float drop_scale, const int32_t* cu_seqlens, void* stream);
 /* dqkv bf16 [B*S, 3*H] from dout bf16 [B*S, H], the saved qkv / out / lse.  drop_*: attention-probability
  * dropout (element index ((b*heads + h)*S + q)*S + key; threshold 0 disables), replayed in the backward. */
 int pgca_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                        const int32_t* key_mask, int32_t B, int32_t S, int32_t heads, int32_t causal,
-                       void* dqkv, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale, void* stream);
+                       void* dqkv, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale,
+                       const int32_t* cu_seqlens, void* stream);
 
 /* ------------------------------------------------------------------ embeddings */
 /* Caption-decoder input (reference model.py:591-601 + modeling_gpt2.py:571-577):
@@ -193,19 +203,25 @@ int pgca_attention_bwd(const void* qkv, const void* out, const void* dout, const
 /* Train-mode extras (all optional): attended is read at row b*att_stride (0 = one shared vector, i.e. b_o);
  * U [B, xheads, H] adds sum_h w(b,h,s) U[b,h,:] with w the replayable dropout multiplier of the 1-key
  * attention weight (drop_x, index (b*xheads + h)*S + s); drop_e is GPT-2's embedding dropout on h0
- * (index m*H + c).  drop_* are HOST pointers to {seed, threshold, scale bits} or NULL. */
+ * (index m*H + c).  drop_* are HOST pointers to {seed, threshold, scale bits} or NULL.
+ * Packed rows: with row_ids (int32 [n_rows]) output row r (and mean/rstd[r]) is position m = row_ids[r] = b*S + t of the
+ * padded batch (ids, positions and every dropout index stay keyed on m); row_ids[r] < 0 marks a filler row, written as
+ * zeros.  Without row_ids n_rows is ignored and all B*S rows are produced. */
 int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t H, const float* wte, const float* wpe,
                    const float* attended, const float* gamma, const float* beta, float eps, float* h0,
                    float* mean, float* rstd, int32_t att_stride, const float* U, int32_t xheads,
-                   const uint32_t* drop_x, const uint32_t* drop_e, void* stream);
+                   const uint32_t* drop_x, const uint32_t* drop_e, const int32_t* row_ids, int32_t n_rows,
+                   void* stream);
 /* Backward of the above given g = dL/dh0 [B*S, H] (f32):
  *   dwpe[s] += sum_b g; through LN (if gamma) -> de; dwte[ids] += de (rows with row_mask==0 skipped:
- *   their gradient is exactly zero); dattended[b] = sum_s de; dgamma/dbeta partials in part[2,nblk,H]. */
+ *   their gradient is exactly zero); dattended[b] = sum_s de; dgamma/dbeta partials in part[2,nblk,H].
+ * Packed rows: with cu_seqlens (int32 [B+1]) g, mean and rstd hold position (b, s) at row cu[b] + s, s < cu[b+1]-cu[b];
+ * positions beyond a sequence's packed length contribute nothing (they are padding: row_mask is 0 there). */
 int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t* row_mask, int32_t B, int32_t S, int32_t H,
                    const float* wte, const float* attended, const float* gamma, const float* mean,
                    const float* rstd, float* dwte, float* dwpe, float* dattended, float* part, int32_t att_stride,
                    const float* U, float* dU, int32_t xheads, const uint32_t* drop_x, const uint32_t* drop_e,
-                   void* stream);
+                   const int32_t* cu_seqlens, void* stream);
 int pgca_embed_bwd_blocks(int32_t B, int32_t S);
 
 /* ViT patch gather (modeling_clip.py:200-218): pixels f32 [B,3,I,I] -> bf16 [B*G*G, ld_out] in the
@@ -267,17 +283,31 @@ int pgca_dpo_loss(const float* pol_w, const float* pol_l, const float* ref_w, co
 int pgca_seq_batch_prepare(const int64_t* ids, const int64_t* mask, int32_t Bq, int32_t S, int32_t* counts,
                            int32_t* mask32, int32_t* row_map, int64_t* targets, int32_t* seq_of_row, int32_t* n_rows,
                            void* stream);
+/* Packed (variable-length) row layout of a right-padded batch: only positions t < len[b] = 1 + (last t with mask[b,t] != 0)
+ * are given a row, sequence after sequence (reference semantics: with a causal AND key-padding mask, a masked mean and a
+ * masked loss - model.py:449-456,1069-1083, SURVEY 3.1 items 6-7 - nothing a padded position computes reaches a loss term or
+ * a gradient).  mask32 int32 [Bq+1, S]: rows 0..Bq-1 as written by pgca_seq_batch_prepare; row Bq is SET TO ONES here.
+ *   lens[Bq]: the packed length of every sequence;
+ *   cu[Bq+2]: cu[b] = first row of sequence b, cu[Bq] = n = sum len, cu[Bq+1] = n rounded up to a multiple of pad_to;
+ *             rows cu[Bq]..cu[Bq+1]-1 are filler (an extra unmasked "sequence" of zero embeddings) that keeps the row
+ *             count a multiple of the GEMM K tile for the weight gradients;
+ *   row_ids[cap]: row_ids[cu[b] + t] = b*S + t; filler rows get -1  (cap >= Bq*S rounded up to pad_to);
+ *   n_packed[2] = {n, n rounded up};
+ *   row_map (optional, in place, with counts from pgca_seq_batch_prepare): b*S + t  ->  cu[b] + t for the compact rows. */
+int pgca_seq_pack_prepare(int32_t* mask32, int32_t Bq, int32_t S, int32_t pad_to, int32_t* lens, int32_t* cu,
+                          int32_t* row_ids, int32_t* n_packed, const int32_t* counts, int32_t* row_map, void* stream);
 /* row_scale[r] = +-dseq[seq_of_row[r]] * (mode & 1 ? 1/count : 1): dLoss/d tok_lp per compact row; mode & 2 negates
  * (the DLOGITS epilogue computes the cross-entropy form softmax - onehot, so it is fed -dLoss/dtok_lp). */
 int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,
                    int32_t mode, float* row_scale, void* stream);
 
 /* ------------------------------------------------------------------ pooling / normalise (Stage 1) */
-/* pooled[b] = sum_s feats[b,s]*mask[b,s] / max(sum_s mask, 1)  (model.py:449-456); feats f32. */
+/* pooled[b] = sum_s feats[b,s]*mask[b,s] / max(sum_s mask, 1)  (model.py:449-456); feats f32.
+ * With cu_seqlens (int32 [B+1]) feats / dfeats are packed: position (b, s) is row cu[b] + s, s < cu[b+1]-cu[b]. */
 int pgca_masked_mean_fwd(const float* feats, const int32_t* mask, int32_t B, int32_t S, int32_t H, float* pooled,
-                         void* stream);
+                         const int32_t* cu_seqlens, void* stream);
 int pgca_masked_mean_bwd(const float* dpooled, const int32_t* mask, int32_t B, int32_t S, int32_t H,
-                         float* dfeats, void* stream);
+                         float* dfeats, const int32_t* cu_seqlens, void* stream);
 /* y = x / max(||x||, 1e-12) (F.normalize, model.py:828-829) and its backward. */
 int pgca_l2norm_fwd(const float* x, int32_t B, int32_t P, float* y, float* norm, void* stream);
 int pgca_l2norm_bwd(const float* dy, const float* y, const float* norm, int32_t B, int32_t P, float* dx,

@@ -9,30 +9,32 @@ using namespace pgca;
 
 namespace pgca {
 int attention_fwd_tiled(const void* qkv, const int32_t* key_mask, int B, int S, int heads, int causal, void* out,
-                        float* lse, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale, void* stream);
+                        float* lse, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale, const int32_t* cu,
+                        void* stream);
 int attention_bwd_tiled(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_mask,
                         int B, int S, int heads, int causal, void* dqkv, uint32_t drop_seed, uint32_t drop_threshold,
-                        float drop_scale, void* stream);
+                        float drop_scale, const int32_t* cu, void* stream);
 }  // namespace pgca
 
 extern "C" int pgca_attention_fwd(const void* qkv, const int32_t* key_mask, int32_t B, int32_t S, int32_t heads,
                                   int32_t causal, void* out, float* lse, uint32_t drop_seed, uint32_t drop_threshold,
-                                  float drop_scale, void* stream) {
+                                  float drop_scale, const int32_t* cu_seqlens, void* stream) {
   if (!qkv || !out || B <= 0 || S <= 0 || heads <= 0 || B > 65535) {
     set_error("pgca_attention_fwd: bad arguments (B=%d S=%d heads=%d)", B, S, heads);
     return PGCA_ERR_INVALID;
   }
-  return attention_fwd_tiled(qkv, key_mask, B, S, heads, causal, out, lse, drop_seed, drop_threshold, drop_scale, stream);
+  return attention_fwd_tiled(qkv, key_mask, B, S, heads, causal, out, lse, drop_seed, drop_threshold, drop_scale,
+                             cu_seqlens, stream);
 }
 
 extern "C" int pgca_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                                   const int32_t* key_mask, int32_t B, int32_t S, int32_t heads, int32_t causal,
                                   void* dqkv, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale,
-                                  void* stream) {
+                                  const int32_t* cu_seqlens, void* stream) {
   if (!qkv || !out || !dout || !lse || !dqkv || B <= 0 || S <= 0 || S > PGCA_ATTN_MAX_S || heads <= 0 || B > 65535) {
     set_error("pgca_attention_bwd: bad arguments (B=%d S=%d heads=%d; S must be <= %d)", B, S, heads, PGCA_ATTN_MAX_S);
     return PGCA_ERR_INVALID;
   }
   return attention_bwd_tiled(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, drop_seed, drop_threshold,
-                             drop_scale, stream);
+                             drop_scale, cu_seqlens, stream);
 }

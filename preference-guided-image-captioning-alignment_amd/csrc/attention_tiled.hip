@@ -85,18 +85,24 @@ __device__ __forceinline__ void store_rows16(const unsigned char* stage, int str
 __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __restrict__ qkv,
                                                                 const int* __restrict__ kmask, int S, int heads,
                                                                 int causal, bf16_t* __restrict__ out,
-                                                                float* __restrict__ lse_o, Drop drop) {
+                                                                float* __restrict__ lse_o, Drop drop,
+                                                                const int* __restrict__ cu, int Sp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + TILE_QKV;
   unsigned char* kms = smem + 2 * TILE_QKV;  // [128] bytes
 
+  // Sp: the PADDED sequence length (geometry of key_mask, lse and the dropout index).  Packed rows (cu != NULL): this
+  // sequence's tokens are rows cu[b] .. cu[b+1]-1 and S is their count; otherwise rows b*Sp .. and S == Sp.
   const int h = blockIdx.x, b = blockIdx.y, qb = blockIdx.z;
+  const int row0 = cu ? cu[b] : b * Sp;
+  if (cu) S = cu[b + 1] - row0;
+  if (qb * TB >= S) return;  // block-uniform: a short (or empty) sequence has no such query block
   const int H = heads * DH, ld = 3 * H;
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, i16 = lane & 15;
-  const bf16_t* base = qkv + (size_t)b * S * ld + h * DH;
+  const bf16_t* base = qkv + (size_t)row0 * ld + h * DH;
 
   const int qw = qb * TB + 16 * w;  // this wave's first query
   const int q = qw + i16;
@@ -117,14 +123,14 @@ __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __
 
   const float scale = 0.125f;
   const int nkt = causal ? qb + 1 : (S + TB - 1) / TB;
-  const unsigned dbase = (((unsigned)b * heads + h) * S + q) * S;
+  const unsigned dbase = (((unsigned)b * heads + h) * Sp + q) * Sp;
 
   for (int kt = 0; kt < nkt; ++kt) {
     const int k0 = kt * TB;
     __syncthreads();  // every wave is done with the previous key tile
     stage_rows(Ks, base + H, ld, k0, S, t);
     stage_rows(Vs, base + 2 * H, ld, k0, S, t);
-    if (t < TB) kms[t] = (k0 + t < S && (!kmask || kmask[b * S + k0 + t] != 0)) ? 1 : 0;
+    if (t < TB) kms[t] = (k0 + t < S && (!kmask || kmask[b * Sp + k0 + t] != 0)) ? 1 : 0;
     __syncthreads();
     if (!wave_on) continue;
 
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
   const float inv = l > 0.f ? 1.f / l : 0.f;
-  if (lane < 16 && q < S && lse_o) lse_o[((size_t)b * heads + h) * S + q] = m_run + __logf(l);
+  if (lane < 16 && q < S && lse_o) lse_o[((size_t)b * heads + h) * Sp + q] = m_run + __logf(l);
 
   __syncthreads();  // Ks is free: it becomes the output staging (wave w uses rows 16w..16w+15 only)
   unsigned char* stage = Ks + (16 * w) * QS;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __
     pk[1] = pack2(oT[dt][2] * inv, oT[dt][3] * inv);
     *reinterpret_cast<u32x2*>(stage + i16 * QS + (dt * 16 + g * 4) * 2) = pk;
   }
-  if (wave_on) store_rows16(stage, QS, out + (size_t)b * S * H + h * DH, H, qw, min(16, S - qw), lane);
+  if (wave_on) store_rows16(stage, QS, out + (size_t)row0 * H + h * DH, H, qw, min(16, S - qw), lane);
 }
 
 // ------------------------------------------------------------------------------------ backward
@@ -218,7 +224,8 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
                                                                 const bf16_t* __restrict__ dO,
                                                                 const float* __restrict__ lse_i,
                                                                 const int* __restrict__ kmask, int S, int heads,
-                                                                int causal, bf16_t* __restrict__ dqkv, Drop drop) {
+                                                                int causal, bf16_t* __restrict__ dqkv, Drop drop,
+                                                                const int* __restrict__ cu, int Sp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + TILE_QKV;
@@ -230,14 +237,17 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
   unsigned char* kms = reinterpret_cast<unsigned char*>(dels + NQB * TB);  // [128]
 
   const int h = blockIdx.x, b = blockIdx.y;
+  const int row0 = cu ? cu[b] : b * Sp;  // packed rows: see the forward
+  if (cu) S = cu[b + 1] - row0;
+  if (S <= 0) return;
   const int H = heads * DH, ld = 3 * H;
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, i16 = lane & 15;
-  const bf16_t* base = qkv + (size_t)b * S * ld + h * DH;
-  const bf16_t* obase = O + (size_t)b * S * H + h * DH;
-  const bf16_t* dobase = dO + (size_t)b * S * H + h * DH;
-  bf16_t* dbase_g = dqkv + (size_t)b * S * ld + h * DH;
+  const bf16_t* base = qkv + (size_t)row0 * ld + h * DH;
+  const bf16_t* obase = O + (size_t)row0 * H + h * DH;
+  const bf16_t* dobase = dO + (size_t)row0 * H + h * DH;
+  bf16_t* dbase_g = dqkv + (size_t)row0 * ld + h * DH;
 
   // row constants of every query: lse and delta[q] = sum_d dO[q,d] O[q,d] (8 lanes per row)
   for (int idx = t; idx < NQB * TB * 8; idx += TNT) {
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
     d += __shfl_xor(d, 4);
     if (c == 0) dels[row] = d;
   }
-  for (int i = t; i < NQB * TB; i += TNT) lses[i] = i < S ? lse_i[((size_t)b * heads + h) * S + i] : 0.f;
+  for (int i = t; i < NQB * TB; i += TNT) lses[i] = i < S ? lse_i[((size_t)b * heads + h) * Sp + i] : 0.f;
 
   f32x4 dq[NQB][4];
 #pragma unroll
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
     // (the barrier that closes the previous pair protects Ks / Vs / kms)
     stage_rows(Ks, base + H, ld, k0, S, t);
     stage_rows(Vs, base + 2 * H, ld, k0, S, t);
-    if (t < TB) kms[t] = (k0 + t < S && (!kmask || kmask[b * S + k0 + t] != 0)) ? 1 : 0;
+    if (t < TB) kms[t] = (k0 + t < S && (!kmask || kmask[b * Sp + k0 + t] != 0)) ? 1 : 0;
     __syncthreads();
     const int keyw = k0 + 16 * w;            // this wave's first key
     const bool has_keys = keyw < S;          // wave-uniform
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
                   const bool ok = kvalid && q < S && (!causal || key <= q);
                   const float pu = ok ? __expf(sa[tt][r] * scale - l4[r]) : 0.f;  // undropped probability
                   // (the key runs along the lanes here, so each element has its own pair hash)
-                  const float m = drop.on() ? drop.mul((((unsigned)b * heads + h) * S + q) * S + key) : 1.f;
+                  const float m = drop.on() ? drop.mul((((unsigned)b * heads + h) * Sp + q) * Sp + key) : 1.f;
                   ds[tt][r] = pu * (da[tt][r] * m - d4[r]) * scale;               // dP = dP_dropped * m
                   pd[tt][r] = pu * m;                                              // dV uses the dropped probabilities
                 }
@@ -424,7 +434,7 @@ constexpr size_t tbwd_lds(int nqb) { return 4 * TILE_QKV + TILE_P + 2 * (size_t)
 
 template <int NQB>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_mask, int B,
-               int S, int heads, int causal, void* dqkv, Drop drop, hipStream_t s) {
+               int S, int heads, int causal, void* dqkv, Drop drop, const int32_t* cu, hipStream_t s) {
   static const hipError_t attr = hipFuncSetAttribute((const void*)attn_bwd_tiled_kernel<NQB>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbwd_lds(NQB));
   if (attr != hipSuccess) {
@@ -432,7 +442,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     return PGCA_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(attn_bwd_tiled_kernel<NQB>, dim3(heads, B), dim3(TNT), tbwd_lds(NQB), s, (const bf16_t*)qkv,
-                     (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, S, heads, causal, (bf16_t*)dqkv, drop);
+                     (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, S, heads, causal, (bf16_t*)dqkv, drop, cu, S);
   return check_launch("pgca_attention_bwd(tiled)");
 }
 
@@ -441,7 +451,8 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 namespace pgca {
 
 int attention_fwd_tiled(const void* qkv, const int32_t* key_mask, int B, int S, int heads, int causal, void* out,
-                        float* lse, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale, void* stream) {
+                        float* lse, uint32_t drop_seed, uint32_t drop_threshold, float drop_scale, const int32_t* cu,
+                        void* stream) {
   static const hipError_t attr = hipFuncSetAttribute((const void*)attn_fwd_tiled_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)TFWD_LDS);
   if (attr != hipSuccess) {
@@ -451,21 +462,21 @@ int attention_fwd_tiled(const void* qkv, const int32_t* key_mask, int B, int S, 
   const int nqb = (S + TB - 1) / TB;
   hipLaunchKernelGGL(attn_fwd_tiled_kernel, dim3(heads, B, nqb), dim3(TNT), TFWD_LDS, (hipStream_t)stream,
                      (const bf16_t*)qkv, key_mask, S, heads, causal, (bf16_t*)out, lse,
-                     Drop{drop_seed, drop_threshold, drop_scale});
+                     Drop{drop_seed, drop_threshold, drop_scale}, cu, S);
   return check_launch("pgca_attention_fwd(tiled)");
 }
 
 int attention_bwd_tiled(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_mask,
                         int B, int S, int heads, int causal, void* dqkv, uint32_t drop_seed, uint32_t drop_threshold,
-                        float drop_scale, void* stream) {
+                        float drop_scale, const int32_t* cu, void* stream) {
   const Drop d{drop_seed, drop_threshold, drop_scale};
   hipStream_t s = (hipStream_t)stream;
   const int nqb = (S + TB - 1) / TB;
   switch (nqb) {
-    case 1: return launch_bwd<1>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, s);
-    case 2: return launch_bwd<2>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, s);
-    case 3: return launch_bwd<3>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, s);
-    case 4: return launch_bwd<4>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, s);
+    case 1: return launch_bwd<1>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, cu, s);
+    case 2: return launch_bwd<2>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, cu, s);
+    case 3: return launch_bwd<3>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, cu, s);
+    case 4: return launch_bwd<4>(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, d, cu, s);
     default:
       set_error("pgca_attention_bwd: S=%d exceeds the %d-token limit of the register-resident dQ accumulators", S,
                 PGCA_ATTN_MAX_S);

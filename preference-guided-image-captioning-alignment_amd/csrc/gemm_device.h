@@ -259,7 +259,8 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
   }
   if (a.drop_threshold) {
     const Drop d{a.drop_seed, a.drop_threshold, a.drop_scale};
-    const unsigned base = (unsigned)row * (unsigned)a.N + (unsigned)col;
+    const unsigned drow = a.drop_rows ? (unsigned)a.drop_rows[row] : (unsigned)row;  // packed rows: hash of the padded position
+    const unsigned base = drow * (unsigned)a.N + (unsigned)col;
     float m0[4], m1[4];
     d.mul4(base, m0);
     d.mul4(base + 4u, m1);
@@ -361,9 +362,11 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
   bf16x8 ax[AUXIN ? 8 : 1];
   float lse[EPI == PGCA_EPI_DLOGITS ? 8 : 1], rsc[EPI == PGCA_EPI_DLOGITS ? 8 : 1];
   long long tgt[EPI == PGCA_EPI_DLOGITS ? 8 : 1];
+  unsigned drow[8];  // row index the dropout hash is keyed on (pgca_gemm_args::drop_rows; dead code without dropout)
 #pragma unroll
   for (int i8 = 0; i8 < 8; ++i8) {
     const int row = mb + i8 * 8 + r8;
+    drow[i8] = (a.drop_threshold && a.drop_rows) ? (unsigned)a.drop_rows[row] : (unsigned)row;
     if (PF == PF_RES) {
       const float* p = a.residual + (size_t)row * a.ld_res + col;
       pre[PF != PF_NONE ? i8 : 0][0] = *reinterpret_cast<const float4*>(p);
@@ -433,7 +436,7 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
           v[j] = (col + j) < a.N ? rsc[q * i8] * (__expf(v[j] - lse[q * i8]) - ((col + j) == tgt[q * i8] ? 1.f : 0.f)) : 0.f;
       }
       if (a.drop_threshold) {
-        const unsigned base = (unsigned)row * (unsigned)a.N + (unsigned)col;
+        const unsigned base = drow[i8] * (unsigned)a.N + (unsigned)col;
         float m0[4], m1[4];
         d.mul4(base, m0);
         d.mul4(base + 4u, m1);

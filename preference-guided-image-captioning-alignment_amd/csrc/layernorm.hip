@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                      const float* __restrict__ add_to, float* __restrict__ dx_out,
                                                      bf16_t* __restrict__ dx_bf, float* __restrict__ part,
-                                                     float* __restrict__ part_extra, Drop drop_add, Drop drop_dx) {
+                                                     float* __restrict__ part_extra, Drop drop_add, Drop drop_dx,
+                                                     const int* __restrict__ drop_rows) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -164,6 +165,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       if (add_to) load_row_f32<NV>(add_to + row * H, H, lane, av);
     }
     const float mean = mean_i[m], rstd = rstd_i[m];
+    // packed token rows: the dropout hashes stay keyed on the token's position in the padded batch
+    const unsigned drow = drop_rows ? (unsigned)drop_rows[row] : (unsigned)row;
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         d.y = rstd * (dy[j].y - c1 - xv[j].y * c2);
         d.z = rstd * (dy[j].z - c1 - xv[j].z * c2);
         d.w = rstd * (dy[j].w - c1 - xv[j].w * c2);
-        const unsigned eidx = (unsigned)row * (unsigned)H + (unsigned)c;
+        const unsigned eidx = drow * (unsigned)H + (unsigned)c;
         if (add_to) {
           float4 a = EXTRA ? av[EXTRA ? j : 0] : *reinterpret_cast<const float4*>(add_to + row * H + c);
           d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
@@ -261,10 +264,20 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
                                                         const float* __restrict__ beta, float eps,
                                                         float* __restrict__ h0, float* __restrict__ mean_o,
                                                         float* __restrict__ rstd_o, int att_stride, XAttn xa,
-                                                        Drop drop_e) {
+                                                        Drop drop_e, const int* __restrict__ row_ids, int n_rows) {
   const int lane = threadIdx.x & 63;
-  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= B * S) return;
+  const int orow = blockIdx.x * 4 + (threadIdx.x >> 6);  // output row; m = the position b*S + s it holds
+  if (orow >= n_rows) return;
+  const int m = row_ids ? row_ids[orow] : orow;
+  if (m < 0) {  // filler row of the packed layout: zeros (finite through every later kernel, zero gradient)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < H) *reinterpret_cast<float4*>(h0 + (size_t)orow * H + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (gamma && lane == 0) { mean_o[orow] = 0.f; rstd_o[orow] = 1.f; }
+    return;
+  }
   const int b = m / S, s = m % S;
   float4 v[NV], t[NV];
   load_row_f32<NV>(wte + (size_t)ids[m] * H, H, lane, v);
@@ -277,7 +290,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
   float mean = 0.f, rstd = 1.f;
   if (gamma) {
     row_stats<NV>(v, H, lane, eps, mean, rstd);
-    if (lane == 0) { mean_o[m] = mean; rstd_o[m] = rstd; }
+    if (lane == 0) { mean_o[orow] = mean; rstd_o[orow] = rstd; }
   }
   load_row_f32<NV>(wpe + (size_t)s * H, H, lane, t);
 #pragma unroll
@@ -298,7 +311,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const long long* __restr
         drop_e.mul4(e, m4);
         y.x *= m4[0]; y.y *= m4[1]; y.z *= m4[2]; y.w *= m4[3];
       }
-      *reinterpret_cast<float4*>(h0 + (size_t)m * H + c) = y;
+      *reinterpret_cast<float4*>(h0 + (size_t)orow * H + c) = y;
     }
   }
 }
@@ -322,7 +335,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ mean_i,
                                                         const float* __restrict__ rstd_i, float* __restrict__ dwte,
                                                         float* __restrict__ datt, float* __restrict__ part,
-                                                        int att_stride, XAttn xa, Drop drop_e, int chunk) {
+                                                        int att_stride, XAttn xa, Drop drop_e, int chunk,
+                                                        const int* __restrict__ cu) {
   extern __shared__ __attribute__((aligned(16))) float red[];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -341,6 +355,9 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
   for (int ch = wid; ch < nchunks; ch += nw) {
     const int mbase = ch * chunk;
     const int b = mbase / S;
+    // packed rows: position (b, s) of the batch lives at row cu[b] + s of g / mean / rstd, for s < len
+    const int prow0 = cu ? cu[b] : b * S;
+    const int plen = cu ? cu[b + 1] - prow0 : S;
     float4 sa[NV], su[NH][NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
@@ -352,11 +369,13 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
     for (int r = 0; r < chunk; ++r) {
       const int m = mbase + r;
       if (row_mask && row_mask[m] == 0) continue;  // gradient of a padded position is exactly zero
-      any = true;
       const int s = m - b * S;
+      if (s >= plen) continue;
+      any = true;
+      const size_t pr = (size_t)(prow0 + s);
       const long long id = ids[m];
       float4 dy[NV];
-      load_row_f32<NV>(g + (size_t)m * H, H, lane, dy);
+      load_row_f32<NV>(g + pr * H, H, lane, dy);
       if (drop_e.on()) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -375,7 +394,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
           for (int j = 0; j < NV; ++j) { xv[j].x += t[j].x; xv[j].y += t[j].y; xv[j].z += t[j].z; xv[j].w += t[j].w; }
         }
         add_head_terms<NV>(xa, b, s, S, H, lane, xv);
-        const float mean = mean_i[m], rstd = rstd_i[m];
+        const float mean = mean_i[pr], rstd = rstd_i[pr];
         float c1 = 0.f, c2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
@@ -458,7 +477,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
 // vector, the gridDim.y batch slices meet through (gridDim.y-way) atomics.
 __global__ __launch_bounds__(256) void wpe_grad_kernel(const float* __restrict__ g, const int* __restrict__ row_mask,
                                                        int B, int S, int H, float* __restrict__ dwpe, Drop drop_e,
-                                                       int bslice) {
+                                                       int bslice, const int* __restrict__ cu) {
   const int h4 = H >> 2;
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= S * h4) return;
@@ -469,7 +488,13 @@ __global__ __launch_bounds__(256) void wpe_grad_kernel(const float* __restrict__
   for (int b = b0; b < b1; ++b) {
     const int m = b * S + s;
     if (row_mask && row_mask[m] == 0) continue;
-    float4 v = *reinterpret_cast<const float4*>(g + (size_t)m * H + c);
+    size_t pr = (size_t)m;
+    if (cu) {
+      const int p0 = cu[b];
+      if (s >= cu[b + 1] - p0) continue;
+      pr = (size_t)(p0 + s);
+    }
+    float4 v = *reinterpret_cast<const float4*>(g + pr * H + c);
     if (drop_e.on()) {
       const unsigned e = (unsigned)m * (unsigned)H + (unsigned)c;
       float m4[4];
@@ -617,7 +642,8 @@ extern "C" int pgca_layernorm_bwd_blocks(int32_t M) {
 extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, const float* x, const int32_t* row_map,
                                   int32_t M, int32_t H, const float* gamma, const float* mean, const float* rstd,
                                   const float* add_to, float* dx_out, void* dx_bf16, float* part, float* part_extra,
-                                  const uint32_t* drop_add, const uint32_t* drop_dx, void* stream) {
+                                  const uint32_t* drop_add, const uint32_t* drop_dx, const int32_t* drop_rows,
+                                  void* stream) {
   if (check_h("pgca_layernorm_bwd", H)) return PGCA_ERR_INVALID;
   if ((!dy_bf16) == (!dy_f32) || !x || !gamma || !mean || !rstd || !dx_out || M <= 0 || (part_extra && !part)) {
     set_error("pgca_layernorm_bwd: bad arguments");
@@ -641,11 +667,11 @@ extern "C" int pgca_layernorm_bwd(const void* dy_bf16, const float* dy_f32, cons
   if (part_extra) {
     DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV, true>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32,
                                        x, row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part,
-                                       part_extra, da, dd));
+                                       part_extra, da, dd, drop_rows));
   } else {
     DISPATCH_NV(nv, hipLaunchKernelGGL((ln_bwd_kernel<NV, false>), grid, block, lds, s, (const bf16_t*)dy_bf16, dy_f32,
                                        x, row_map, M, H, gamma, mean, rstd, add_to, dx_out, (bf16_t*)dx_bf16, part,
-                                       part_extra, da, dd));
+                                       part_extra, da, dd, drop_rows));
   }
   return check_launch("pgca_layernorm_bwd");
 }
@@ -705,18 +731,22 @@ static Drop drop_from_words(const uint32_t* d) {
 extern "C" int pgca_embed_fwd(const int64_t* ids, int32_t B, int32_t S, int32_t H, const float* wte, const float* wpe,
                               const float* attended, const float* gamma, const float* beta, float eps, float* h0,
                               float* mean, float* rstd, int32_t att_stride, const float* U, int32_t xheads,
-                              const uint32_t* drop_x, const uint32_t* drop_e, void* stream) {
+                              const uint32_t* drop_x, const uint32_t* drop_e, const int32_t* row_ids, int32_t n_rows,
+                              void* stream) {
   if (check_h("pgca_embed_fwd", H)) return PGCA_ERR_INVALID;
-  if (!ids || !wte || !wpe || !h0 || B <= 0 || S <= 0 || (gamma && (!beta || !mean || !rstd))) {
+  if (!ids || !wte || !wpe || !h0 || B <= 0 || S <= 0 || (gamma && (!beta || !mean || !rstd)) ||
+      (row_ids && n_rows <= 0)) {
     set_error("pgca_embed_fwd: bad arguments");
     return PGCA_ERR_INVALID;
   }
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((B * S + 3) / 4), block(256);
+  if (!row_ids) n_rows = B * S;
+  dim3 grid((n_rows + 3) / 4), block(256);
   const XAttn xa{U, nullptr, xheads, drop_from_words(drop_x)};
   const Drop de = drop_from_words(drop_e);
   DISPATCH_NV(nv_for(H), hipLaunchKernelGGL((embed_fwd_kernel<NV>), grid, block, 0, s, (const long long*)ids, B, S, H,
-                                            wte, wpe, attended, gamma, beta, eps, h0, mean, rstd, att_stride, xa, de));
+                                            wte, wpe, attended, gamma, beta, eps, h0, mean, rstd, att_stride, xa, de,
+                                            row_ids, n_rows));
   return check_launch("pgca_embed_fwd");
 }
 
@@ -736,7 +766,8 @@ extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t*
                               int32_t H, const float* wte, const float* attended, const float* gamma,
                               const float* mean, const float* rstd, float* dwte, float* dwpe, float* dattended,
                               float* part, int32_t att_stride, const float* U, float* dU, int32_t xheads,
-                              const uint32_t* drop_x, const uint32_t* drop_e, void* stream) {
+                              const uint32_t* drop_x, const uint32_t* drop_e, const int32_t* cu_seqlens,
+                              void* stream) {
   if (check_h("pgca_embed_bwd", H)) return PGCA_ERR_INVALID;
   if (!g || !ids || !dwte || !dwpe || B <= 0 || S <= 0 || (gamma && (!wte || !mean || !rstd || !part))) {
     set_error("pgca_embed_bwd: bad arguments");
@@ -752,11 +783,11 @@ extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t*
   if (nv <= 4 && xheads <= 8) {
     DISPATCH_NV(nv, hipLaunchKernelGGL((embed_bwd_kernel<(NV <= 4 ? NV : 4), true>), grid, block, lds, s, g,
                                        (const long long*)ids, row_mask, B, S, H, wte, attended, gamma, mean, rstd, dwte,
-                                       dattended, part, att_stride, xa, de, chunk));
+                                       dattended, part, att_stride, xa, de, chunk, cu_seqlens));
   } else {
     DISPATCH_NV(nv, hipLaunchKernelGGL((embed_bwd_kernel<NV, false>), grid, block, lds, s, g, (const long long*)ids,
                                        row_mask, B, S, H, wte, attended, gamma, mean, rstd, dwte, dattended, part,
-                                       att_stride, xa, de, chunk));
+                                       att_stride, xa, de, chunk, cu_seqlens));
   }
   {
     const int nthr = S * (H >> 2);
@@ -764,7 +795,7 @@ extern "C" int pgca_embed_bwd(const float* g, const int64_t* ids, const int32_t*
     const int bslice = (B + ys - 1) / ys;
     ys = (B + bslice - 1) / bslice;
     hipLaunchKernelGGL(wpe_grad_kernel, dim3((nthr + 255) / 256, ys), dim3(256), 0, s, g, row_mask, B, S, H, dwpe, de,
-                       bslice);
+                       bslice, cu_seqlens);
   }
   return check_launch("pgca_embed_bwd");
 }

@@ -213,30 +213,86 @@ __global__ void seq_compact_kernel(const long long* __restrict__ ids, const long
   }
 }
 
+// Packed row layout (pgca_seq_pack_prepare): lens[b] = 1 + last position with a non-zero mask (0 for an empty sequence).
+__global__ void seq_lens_kernel(const int* __restrict__ mask32, int Bq, int S, int* __restrict__ lens) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= Bq) return;
+  int len = 0;
+  for (int t = lane; t < S; t += 64)
+    if (mask32[(size_t)b * S + t] != 0) len = t + 1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) len = max(len, __shfl_xor(len, o));
+  if (lane == 0) lens[b] = len;
+}
+// One wave per sequence (+ one for the filler tail, b == Bq): offsets, row ids, the filler, and the compact rows' map.
+__global__ void seq_pack_kernel(const int* __restrict__ lens, int Bq, int S, int pad_to, int* __restrict__ cu,
+                                int* __restrict__ row_ids, int* __restrict__ n_packed, int* __restrict__ mask32,
+                                const int* __restrict__ counts, int* __restrict__ row_map) {
+  const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b > Bq) return;
+  int off = 0, coff = 0;  // exclusive prefixes of the lengths and of the scored-row counts
+  for (int i = lane; i < b; i += 64) {
+    off += lens[i];
+    if (counts) coff += counts[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    off += __shfl_xor(off, o);
+    coff += __shfl_xor(coff, o);
+  }
+  if (b == Bq) {  // filler: rows off .. padded-1, an unmasked pseudo-sequence
+    const int padded = (off + pad_to - 1) / pad_to * pad_to;
+    if (lane == 0) {
+      cu[Bq] = off;
+      cu[Bq + 1] = padded;
+      n_packed[0] = off;
+      n_packed[1] = padded;
+    }
+    for (int r = off + lane; r < padded; r += 64) row_ids[r] = -1;
+    for (int t = lane; t < S; t += 64) mask32[(size_t)Bq * S + t] = 1;
+    return;
+  }
+  if (lane == 0) cu[b] = off;
+  const int len = lens[b];
+  for (int t = lane; t < len; t += 64) row_ids[off + t] = b * S + t;
+  if (row_map) {
+    const int n = counts[b];
+    for (int r = lane; r < n; r += 64) row_map[coff + r] += off - b * S;
+  }
+}
+
 // ------------------------------------------------------------------------------------ pooling / normalise
+// cu (optional): packed rows - position (b, t) is row cu[b] + t of f / df, for t < cu[b+1] - cu[b] (every position with a
+// non-zero mask lies below that length by construction: pgca_seq_pack_prepare)
 __global__ void masked_mean_fwd_kernel(const float* __restrict__ f, const int* __restrict__ mask, int S, int H,
-                                       float* __restrict__ pooled) {
+                                       float* __restrict__ pooled, const int* __restrict__ cu) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= H) return;
+  const size_t r0 = cu ? (size_t)cu[b] : (size_t)b * S;
+  const int len = cu ? cu[b + 1] - cu[b] : S;
   float s = 0.f;
   int cnt = 0;
   for (int t = 0; t < S; ++t) {
     const int m = mask[b * S + t];
     cnt += m;
-    if (m) s += f[((size_t)b * S + t) * H + c] * (float)m;
+    if (m && t < len) s += f[(r0 + t) * H + c] * (float)m;
   }
   pooled[(size_t)b * H + c] = s / (float)(cnt < 1 ? 1 : cnt);
 }
 __global__ void masked_mean_bwd_kernel(const float* __restrict__ dp, const int* __restrict__ mask, int S, int H,
-                                       float* __restrict__ df) {
+                                       float* __restrict__ df, const int* __restrict__ cu) {
   const int b = blockIdx.y;
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= H) return;
+  const size_t r0 = cu ? (size_t)cu[b] : (size_t)b * S;
+  const int len = cu ? cu[b + 1] - cu[b] : S;
   int cnt = 0;
   for (int t = 0; t < S; ++t) cnt += mask[b * S + t];
   const float g = dp[(size_t)b * H + c] / (float)(cnt < 1 ? 1 : cnt);
-  for (int t = 0; t < S; ++t) df[((size_t)b * S + t) * H + c] = g * (float)mask[b * S + t];
+  for (int t = 0; t < len; ++t) df[(r0 + t) * H + c] = g * (float)mask[b * S + t];
 }
 
 // one wave per row
@@ -587,6 +643,17 @@ extern "C" int pgca_seq_batch_prepare(const int64_t* ids, const int64_t* mask, i
   return check_launch("pgca_seq_batch_prepare");
 }
 
+extern "C" int pgca_seq_pack_prepare(int32_t* mask32, int32_t Bq, int32_t S, int32_t pad_to, int32_t* lens, int32_t* cu,
+                                     int32_t* row_ids, int32_t* n_packed, const int32_t* counts, int32_t* row_map,
+                                     void* stream) {
+  REQUIRE(mask32 && lens && cu && row_ids && n_packed && Bq > 0 && S > 0 && pad_to > 0 && (!row_map || counts),
+          "pgca_seq_pack_prepare");
+  hipLaunchKernelGGL(seq_lens_kernel, dim3((Bq + 3) / 4), dim3(256), 0, (hipStream_t)stream, mask32, Bq, S, lens);
+  hipLaunchKernelGGL(seq_pack_kernel, dim3((Bq + 1 + 3) / 4), dim3(256), 0, (hipStream_t)stream, lens, Bq, S, pad_to,
+                     cu, row_ids, n_packed, mask32, counts, row_map);
+  return check_launch("pgca_seq_pack_prepare");
+}
+
 extern "C" int pgca_row_scale(const float* dseq, const int32_t* seq_of_row, const int32_t* seq_count, int32_t nrows,
                               int32_t mode, float* row_scale, void* stream) {
   REQUIRE(dseq && seq_of_row && row_scale && nrows > 0 && (!(mode & 1) || seq_count), "pgca_row_scale");
@@ -605,17 +672,17 @@ extern "C" int pgca_dpo_loss(const float* pol_w, const float* pol_l, const float
 }
 
 extern "C" int pgca_masked_mean_fwd(const float* feats, const int32_t* mask, int32_t B, int32_t S, int32_t H,
-                                    float* pooled, void* stream) {
+                                    float* pooled, const int32_t* cu_seqlens, void* stream) {
   REQUIRE(feats && mask && pooled && B > 0 && S > 0 && H > 0, "pgca_masked_mean_fwd");
   hipLaunchKernelGGL(masked_mean_fwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, feats, mask,
-                     S, H, pooled);
+                     S, H, pooled, cu_seqlens);
   return check_launch("pgca_masked_mean_fwd");
 }
 extern "C" int pgca_masked_mean_bwd(const float* dpooled, const int32_t* mask, int32_t B, int32_t S, int32_t H,
-                                    float* dfeats, void* stream) {
+                                    float* dfeats, const int32_t* cu_seqlens, void* stream) {
   REQUIRE(dpooled && mask && dfeats && B > 0 && S > 0 && H > 0, "pgca_masked_mean_bwd");
   hipLaunchKernelGGL(masked_mean_bwd_kernel, dim3((H + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dpooled, mask,
-                     S, H, dfeats);
+                     S, H, dfeats, cu_seqlens);
   return check_launch("pgca_masked_mean_bwd");
 }
 

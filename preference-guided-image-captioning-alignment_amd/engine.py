@@ -28,6 +28,10 @@ ATTN_BWD_MAX_S = 512   # include/pgca_hip.h PGCA_ATTN_MAX_S
 class Workspace:
     """Named, reusable device buffers (allocated on first use, reused every step)."""
 
+    # packed (variable-length) batches change their row count from step to step: a buffer that has to GROW is given this
+    # much head-room, so the first few batches settle the sizes and later ones only re-slice
+    GROW = 1.125
+
     def __init__(self, device):
         self.device = torch.device(device)
         self.bufs: Dict[str, torch.Tensor] = {}
@@ -39,7 +43,8 @@ class Workspace:
             n *= s
         t = self.bufs.get(key)
         if t is None or t.dtype != dtype or t.numel() < n:
-            t = torch.empty(max(n, 1), dtype=dtype, device=self.device)
+            grow = t is not None and t.dtype == dtype
+            t = torch.empty(max(int(n * self.GROW) if grow else n, 1), dtype=dtype, device=self.device)
             self.bufs[key] = t
         v = t[:n].view(shape)
         if zero:
@@ -109,6 +114,27 @@ class DropoutPlan:
 
 
 # ------------------------------------------------------------------------------------------ batches
+PACK_PAD = 64   # packed row counts are rounded up to the K tile of the weight-gradient GEMMs (zero filler rows)
+
+
+@dataclass
+class RowPack:
+    """Packed (variable-length) row layout of a right-padded [Bq, S] batch: only positions ``t < len[b]`` (``len`` = 1 +
+    last unmasked position) own a row, sequence after sequence, followed by ``Mp - n`` zero filler rows that round the
+    row count up to ``PACK_PAD``.  Nothing a padded position computes reaches a loss term or a gradient (causal AND
+    key-padding mask, masked mean, masked loss: reference model.py:449-456,1069-1083), so the
+    trunk runs on these rows only.  Positions, key masks, log-sum-exps and every dropout index stay keyed on the padded
+    (b, t), so a packed launch reproduces the padded one token for token."""
+    cu: torch.Tensor        # [Bq+2] int32: first row of each sequence; cu[Bq] = n, cu[Bq+1] = Mp (the filler "sequence")
+    row_ids: torch.Tensor   # [Mp] int32: padded position b*S + t of each row, -1 for filler rows
+    mask: torch.Tensor      # [Bq+1, S] int32 key mask; the extra last row (the filler's) is ones
+    lens: torch.Tensor      # [Bq] int32
+    n: int                  # rows that hold a token
+    Mp: int                 # rows incl. filler (multiple of PACK_PAD)
+    Bq: int
+    S: int
+
+
 @dataclass
 class SeqBatch:
     """Token batch + the integer index work of the loss, prepared once per batch.
@@ -127,30 +153,81 @@ class SeqBatch:
     n_rows: int
     Bq: int
     S: int
+    pack: Optional[RowPack] = None          # packed row layout of the same batch
+    row_map_packed: Optional[torch.Tensor] = None   # [Mc] int32: row_map in packed row numbers
+
+
+class PendingRowPack:
+    """Row-pack index preparation issued on the current stream; ``result()`` waits for the two row counts."""
+
+    def __init__(self, mask1, lens, cu, row_ids, n_host, event, Bq, S):
+        self._f, self._n, self._ev, self.Bq, self.S = (mask1, lens, cu, row_ids), n_host, event, Bq, S
+
+    def result(self) -> RowPack:
+        self._ev.synchronize()
+        n, Mp = int(self._n[0]), int(self._n[1])
+        mask1, lens, cu, row_ids = self._f
+        return RowPack(cu=cu, row_ids=row_ids[:max(Mp, 1)], mask=mask1, lens=lens, n=n, Mp=Mp, Bq=self.Bq, S=self.S)
+
+
+def _issue_pack(mask1: torch.Tensor, Bq: int, S: int, counts=None, row_map=None):
+    dev = mask1.device
+    cap = (Bq * S + PACK_PAD - 1) // PACK_PAD * PACK_PAD
+    lens = torch.empty(Bq, dtype=I32, device=dev)
+    cu = torch.empty(Bq + 2, dtype=I32, device=dev)
+    row_ids = torch.empty(cap, dtype=I32, device=dev)
+    n_dev = torch.empty(2, dtype=I32, device=dev)
+    hip.seq_pack_prepare(mask1, Bq, S, PACK_PAD, lens, cu, row_ids, n_dev, counts=counts, row_map=row_map)
+    return lens, cu, row_ids, n_dev
+
+
+def prepare_row_pack_async(mask32: torch.Tensor) -> PendingRowPack:
+    """mask32 [Bq, S] int32 on the device (0/1) -> the packed row layout (Stage 1: no log-prob index work)."""
+    Bq, S = mask32.shape
+    mask1 = torch.empty(Bq + 1, S, dtype=I32, device=mask32.device)
+    mask1[:Bq].copy_(mask32)
+    lens, cu, row_ids, n_dev = _issue_pack(mask1, Bq, S)
+    n_host = torch.empty(2, dtype=I32, pin_memory=True)
+    n_host.copy_(n_dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return PendingRowPack(mask1, lens, cu, row_ids, n_host, ev, Bq, S)
+
+
+def make_row_pack(mask32: torch.Tensor) -> RowPack:
+    return prepare_row_pack_async(mask32).result()
 
 
 class PendingSeqBatch:
     """Index preparation issued on the current stream; ``result()`` waits for the one number the host needs (how many
     rows are scored - it sizes the LM-head launch) and hands out the views."""
 
-    def __init__(self, ids, mask32, row_map, targets, seq_of_row, counts, n_host, event, Bq, S):
-        self._f = (ids, mask32, row_map, targets, seq_of_row, counts)
-        self._n, self._ev, self.Bq, self.S = n_host, event, Bq, S
+    def __init__(self, ids, mask1, row_map, targets, seq_of_row, counts, n_host, event, Bq, S, pack=None):
+        self._f = (ids, mask1, row_map, targets, seq_of_row, counts)
+        self._n, self._ev, self.Bq, self.S, self._pack = n_host, event, Bq, S, pack
 
     def result(self) -> "SeqBatch":
         self._ev.synchronize()
         n = int(self._n[0])
         if n <= 0:
             raise ValueError("no scored token in the batch (every caption has <= 1 real token)")
-        ids, mask32, row_map, targets, seq_of_row, counts = self._f
-        return SeqBatch(ids=ids, mask=mask32, row_map=row_map[:n], targets=targets[:n], seq_of_row=seq_of_row[:n],
-                        counts=counts, n_rows=n, Bq=self.Bq, S=self.S)
+        ids, mask1, row_map, targets, seq_of_row, counts = self._f
+        pack, rmp = None, None
+        if self._pack is not None:
+            lens, cu, row_ids, rmp = self._pack
+            npk, Mp = int(self._n[1]), int(self._n[2])
+            pack = RowPack(cu=cu, row_ids=row_ids[:Mp], mask=mask1, lens=lens, n=npk, Mp=Mp, Bq=self.Bq, S=self.S)
+            rmp = rmp[:n]
+        return SeqBatch(ids=ids, mask=mask1[:self.Bq], row_map=row_map[:n], targets=targets[:n],
+                        seq_of_row=seq_of_row[:n], counts=counts, n_rows=n, Bq=self.Bq, S=self.S, pack=pack,
+                        row_map_packed=rmp)
 
 
-def prepare_seq_batch_async(ids: torch.Tensor, mask: torch.Tensor, device) -> PendingSeqBatch:
+def prepare_seq_batch_async(ids: torch.Tensor, mask: torch.Tensor, device, pack: bool = True) -> PendingSeqBatch:
     """``ids`` / ``mask`` [Bq, S] on the host (pinned: the copy is asynchronous) or on the device.  Everything -
-    the int32 key mask, the shifted gather indices, the compaction, the per-sequence counts - runs on the current HIP
-    stream (``pgca_seq_batch_prepare``); nothing is computed on the host."""
+    the int32 key mask, the shifted gather indices, the compaction, the per-sequence counts and (``pack``) the packed
+    row layout - runs on the current HIP stream (``pgca_seq_batch_prepare`` / ``pgca_seq_pack_prepare``); nothing is
+    computed on the host."""
     dev = torch.device(device)
     ids_d = ids.detach().to(dev, I64, non_blocking=True).contiguous()
     mask_d = mask.detach().to(dev, I64, non_blocking=True).contiguous()
@@ -158,23 +235,29 @@ def prepare_seq_batch_async(ids: torch.Tensor, mask: torch.Tensor, device) -> Pe
     if S < 2:
         raise ValueError("sequences need at least 2 positions (the first token is never scored)")
     cap = Bq * (S - 1)
-    mask32 = torch.empty(Bq, S, dtype=I32, device=dev)
+    mask1 = torch.empty(Bq + 1, S, dtype=I32, device=dev)   # + the key-mask row of the packed layout's filler
     counts = torch.empty(Bq, dtype=I32, device=dev)
     row_map = torch.empty(cap, dtype=I32, device=dev)
     targets = torch.empty(cap, dtype=I64, device=dev)
     seq_of_row = torch.empty(cap, dtype=I32, device=dev)
-    n_dev = torch.empty(1, dtype=I32, device=dev)
-    hip.seq_batch_prepare(ids_d, mask_d, Bq, S, counts, mask32, row_map, targets, seq_of_row, n_dev)
-    n_host = torch.empty(1, dtype=I32, pin_memory=True)
+    n_dev = torch.empty(3, dtype=I32, device=dev)
+    hip.seq_batch_prepare(ids_d, mask_d, Bq, S, counts, mask1, row_map, targets, seq_of_row, n_dev)
+    pk = None
+    if pack:
+        rmp = row_map.clone()
+        lens, cu, row_ids, n2 = _issue_pack(mask1, Bq, S, counts=counts, row_map=rmp)
+        n_dev[1:].copy_(n2)
+        pk = (lens, cu, row_ids, rmp)
+    n_host = torch.empty(3, dtype=I32, pin_memory=True)
     n_host.copy_(n_dev, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    return PendingSeqBatch(ids_d, mask32, row_map, targets, seq_of_row, counts, n_host, ev, Bq, S)
+    return PendingSeqBatch(ids_d, mask1, row_map, targets, seq_of_row, counts, n_host, ev, Bq, S, pk)
 
 
-def make_seq_batch(ids: torch.Tensor, mask: torch.Tensor, device) -> SeqBatch:
-    """Token batch + index work of the loss, prepared on the device (one host wait: the scored-row count)."""
-    return prepare_seq_batch_async(ids, mask, device).result()
+def make_seq_batch(ids: torch.Tensor, mask: torch.Tensor, device, pack: bool = True) -> SeqBatch:
+    """Token batch + index work of the loss, prepared on the device (one host wait: the row counts)."""
+    return prepare_seq_batch_async(ids, mask, device, pack).result()
 
 
 # ------------------------------------------------------------------------------------------ helpers
@@ -235,9 +318,11 @@ class GptTrunk:
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
 
     def forward(self, h0: torch.Tensor, mask: Optional[torch.Tensor], Bq: int, S: int, save: bool,
-                drop=None) -> torch.Tensor:
+                drop=None, pack: Optional[RowPack] = None) -> torch.Tensor:
         """h0 [Bq*S, H] f32 (already including positions) -> residual stream after the last block.
-        ``drop(layer, kind)`` (optional) yields the dropout triple of a site (train mode)."""
+        ``drop(layer, kind)`` (optional) yields the dropout triple of a site (train mode).
+        ``pack``: h0 holds the packed rows [pack.Mp, H] instead (``RowPack``): every kernel runs on those rows only, the
+        attention takes the sequence offsets, and the dropout sites hash the padded position of each row."""
         a, H, I = self.arch, self.arch.hidden, self.arch.inner
         if S > a.n_pos:
             raise ValueError(f"sequence length {S} exceeds GPT-2's {a.n_pos} learned positions")
@@ -245,8 +330,12 @@ class GptTrunk:
             raise ValueError(f"training needs sequence length <= {ATTN_BWD_MAX_S} (attention backward keeps the query "
                              f"gradients of every 128-token block in registers); got {S}")
         M = Bq * S
+        cu = rows = None
+        nseq = Bq
+        if pack is not None:   # the filler rows are one more (unmasked) sequence of the attention launch
+            M, cu, rows, mask, nseq = pack.Mp, pack.cu, pack.row_ids, pack.mask, Bq + 1
         L = len(self.layers)
-        sv = {"M": M, "Bq": Bq, "S": S, "mask": mask, "drop": drop} if save else None
+        sv = {"M": M, "Bq": Bq, "S": S, "mask": mask, "drop": drop, "pack": pack} if save else None
         dsite = (lambda li, kind: drop(li, kind)) if drop is not None else (lambda li, kind: None)
         h = h0
         for li, P in enumerate(self.layers):
@@ -258,11 +347,11 @@ class GptTrunk:
             qkv = self._buf(k + "qkv", (M, 3 * H), BF16)
             hip.gemm(ln1, P["wqkv"].b, M, 3 * H, H, hip.NN, bias=P["bqkv"].w, out_bf16=qkv)
             att = self._buf(k + "att", (M, H), BF16)
-            lse = self._buf(k + "lse", (Bq, a.heads, S), F32)
-            hip.attention_fwd(qkv, mask, Bq, S, a.heads, True, att, lse, drop=dsite(li, KIND_ATTN))
+            lse = self._buf(k + "lse", (nseq, a.heads, S), F32)
+            hip.attention_fwd(qkv, mask, nseq, S, a.heads, True, att, lse, drop=dsite(li, KIND_ATTN), cu=cu)
             hm = self._buf(k + "hm", (M, H), F32) if save else h
             hip.gemm(att, P["wo"].b, M, H, H, hip.NN, bias=P["bo"].w, residual=h, out_f32=hm,
-                     drop=dsite(li, KIND_RESID_ATTN))
+                     drop=dsite(li, KIND_RESID_ATTN), drop_rows=rows)
             ln2 = self._buf(k + "ln2", (M, H), BF16)
             m2 = self._buf(k + "m2", (M,), F32)
             r2 = self._buf(k + "r2", (M,), F32)
@@ -273,7 +362,7 @@ class GptTrunk:
                      aux_out=pre)
             hn = self._buf(f"l{li + 1}.hin", (M, H), F32) if save else hm
             hip.gemm(act, P["wpr"].b, M, H, I, hip.NN, bias=P["bpr"].w, residual=hm, out_f32=hn,
-                     drop=dsite(li, KIND_RESID_MLP))
+                     drop=dsite(li, KIND_RESID_MLP), drop_rows=rows)
             if save:
                 sv[li] = dict(hin=h, ln1=ln1, m1=m1, r1=r1, qkv=qkv, att=att, lse=lse, hm=hm, ln2=ln2, m2=m2, r2=r2,
                               act=act, pre=pre)
@@ -301,6 +390,8 @@ class GptTrunk:
         assert sv is not None, "forward(save=True) must precede backward"
         a, H, I = self.arch, self.arch.hidden, self.arch.inner
         M, Bq, S = sv["M"], sv["Bq"], sv["S"]
+        pack: Optional[RowPack] = sv.get("pack")
+        cu, rows, nseq = (pack.cu, pack.row_ids, Bq + 1) if pack is not None else (None, None, Bq)
         ws = self.ws
         nb = hip.layernorm_bwd_blocks(M)
         part4 = ws.get("ln_part", (4, nb, H), F32)   # planes: dgamma, dbeta, sum(add_to), sum(dx_out)
@@ -345,7 +436,7 @@ class GptTrunk:
             g2_bf = self._buf("gbf_b" if (li & 1) else "gbf_a", (M, H), BF16)
             hip.layernorm_bwd(s["hm"], M, H, P["ln2w"].w, s["m2"], s["r2"], g2, dy_bf16=dln, add_to=g, dx_bf16=g2_bf,
                               part=part, part_extra=partx, drop_add=dsite(li, KIND_RESID_MLP),
-                              drop_dx=dsite(li, KIND_RESID_ATTN))
+                              drop_dx=dsite(li, KIND_RESID_ATTN), drop_rows=rows)
             # the same pass summed g (bias gradient of mlp.c_proj) and g2 (bias gradient of attn.c_proj)
             _ln_param_grads(part4, nb, H, P["ln2w"].g, P["ln2b"].g, P["bpr"].g, P["bo"].g)
             # ---- attention: hm = hin + c_proj(attn(c_attn(ln1(hin))))
@@ -353,8 +444,8 @@ class GptTrunk:
             hip.gemm(g2_bf, P["wo"].b, M, H, H, hip.NT, out_bf16=datt)
             wgrads.append((s["att"], g2_bf, H, H, M, P["wo"].g))
             dqkv = self._buf("dqkv" + par, (M, 3 * H), BF16)
-            hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], Bq, S, a.heads, True, dqkv,
-                              drop=dsite(li, KIND_ATTN))
+            hip.attention_bwd(s["qkv"], s["att"], datt, s["lse"], sv["mask"], nseq, S, a.heads, True, dqkv,
+                              drop=dsite(li, KIND_ATTN), cu=cu)
             hip.gemm(dqkv, P["wqkv"].b, M, H, 3 * H, hip.NT, out_bf16=dln)
             wgrads.append((s["ln1"], dqkv, H, 3 * H, M, P["wqkv"].g))
             # one launch, whole K per tile: no split-K atomics (gemm256_group_tn_kernel)
@@ -374,7 +465,7 @@ class GptTrunk:
             settle(li + 1)   # that launch read its incoming g_bf from the buffer g3_bf is about to overwrite
             hip.layernorm_bwd(s["hin"], M, H, P["ln1w"].w, s["m1"], s["r1"], g3, dy_bf16=dln, add_to=g2,
                               dx_bf16=g3_bf, part=part,
-                              drop_dx=dsite(li - 1, KIND_RESID_MLP) if li > 0 else None)
+                              drop_dx=dsite(li - 1, KIND_RESID_MLP) if li > 0 else None, drop_rows=rows)
             _ln_param_grads(part, nb, H, P["ln1w"].g, P["ln1b"].g)
             g, g_bf = g3, g3_bf
             if side is None and self.grad_hook is not None:
@@ -701,34 +792,39 @@ class CaptionDecoderEngine:
                      ld_out_f32=XH * H)
         return dict(emb_bf=emb_bf, pv=pv, pv_raw=pv_raw, vv=vv, att=None, U=U)
 
-    def hidden(self, emb: torch.Tensor, sb: SeqBatch, save: bool, drop=None) -> torch.Tensor:
-        """Residual stream after the last block, [Bq*S, H] f32.  ``drop(layer, kind)``: train-mode dropout sites."""
+    def hidden(self, emb: torch.Tensor, sb: SeqBatch, save: bool, drop=None, packed: bool = False) -> torch.Tensor:
+        """Residual stream after the last block, [Bq*S, H] f32 - or, ``packed``, the rows of ``sb.pack`` only
+        ([pack.Mp, H]: the padded positions are never computed).  ``drop(layer, kind)``: train-mode dropout sites."""
         a = self.arch.gpt
         H, Bq, S, XH = a.hidden, sb.Bq, sb.S, self.arch.xattn_heads
-        M = Bq * S
+        pack = sb.pack if packed else None
+        if packed and pack is None:
+            raise ValueError("packed=True needs a SeqBatch prepared with pack=True")
+        M = pack.Mp if pack is not None else Bq * S
+        pk = dict(row_ids=pack.row_ids, n_rows=M) if pack is not None else {}
         pf = self._prefix(emb, Bq, drop)
         h0 = self._buf("h0", (M, H), F32)
         m0, r0 = self._buf("m0", (M,), F32), self._buf("r0", (M,), F32)
         if drop is None:
             hip.embed_fwd(sb.ids, Bq, S, H, self.wte.w, self.wpe.w, h0, attended=pf["att"], gamma=self.anw.w,
-                          beta=self.anb.w, eps=1e-5, mean=m0, rstd=r0)
+                          beta=self.anb.w, eps=1e-5, mean=m0, rstd=r0, **pk)
         else:
             hip.embed_fwd(sb.ids, Bq, S, H, self.wte.w, self.wpe.w, h0, attended=self.ob.w, att_stride=0,
                           gamma=self.anw.w, beta=self.anb.w, eps=1e-5, mean=m0, rstd=r0, U=pf["U"], xheads=XH,
-                          drop_x=drop(0, KIND_XATTN), drop_e=drop(0, KIND_EMBD))
-        hL = self.trunk.forward(h0, sb.mask, Bq, S, save, drop)
+                          drop_x=drop(0, KIND_XATTN), drop_e=drop(0, KIND_EMBD), **pk)
+        hL = self.trunk.forward(h0, sb.mask, Bq, S, save, drop, pack=pack)
         if save:
-            self.saved = dict(sb=sb, m0=m0, r0=r0, hL=hL, drop=drop, **pf)
+            self.saved = dict(sb=sb, m0=m0, r0=r0, hL=hL, drop=drop, pack=pack, **pf)
         return hL
 
-    def token_logprobs(self, hL: torch.Tensor, sb: SeqBatch, save: bool) -> torch.Tensor:
+    def token_logprobs(self, hL: torch.Tensor, sb: SeqBatch, save: bool, packed: bool = False) -> torch.Tensor:
         """ln_f on the scored rows only, then the fused LM head: tok_lp [Mc] f32."""
         a = self.arch.gpt
         H, Mc = a.hidden, sb.n_rows
         hf = self._buf("hf", (Mc, H), BF16)
         mf, rf = self._buf("mf", (Mc,), F32), self._buf("rf", (Mc,), F32)
-        hip.layernorm_fwd(hL, Mc, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, row_map=sb.row_map, y_bf16=hf,
-                          mean=mf, rstd=rf)
+        hip.layernorm_fwd(hL, Mc, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps,
+                          row_map=sb.row_map_packed if packed else sb.row_map, y_bf16=hf, mean=mf, rstd=rf)
         nparts = 2 * (self.Vp // 128)
         smax = self._buf("smax", (Mc, nparts), F32)
         ssum = self._buf("ssum", (Mc, nparts), F32)
@@ -742,10 +838,13 @@ class CaptionDecoderEngine:
             self.saved.update(hf=hf, mf=mf, rf=rf, lse=lse)
         return tok
 
-    def sequence_logprobs(self, emb: torch.Tensor, sb: SeqBatch, reduce: str, save: bool, drop=None) -> torch.Tensor:
-        """seq_lp [Bq]: 'sum' (components.py:357-362) or 'mean' (model.py:1082-1083)."""
-        hL = self.hidden(emb, sb, save, drop)
-        tok = self.token_logprobs(hL, sb, save)
+    def sequence_logprobs(self, emb: torch.Tensor, sb: SeqBatch, reduce: str, save: bool, drop=None,
+                          packed: Optional[bool] = None) -> torch.Tensor:
+        """seq_lp [Bq]: 'sum' (components.py:357-362) or 'mean' (model.py:1082-1083).  ``packed`` (default: whenever the
+        batch carries a packed layout) runs the trunk on the real tokens' rows only."""
+        packed = (sb.pack is not None) if packed is None else bool(packed)
+        hL = self.hidden(emb, sb, save, drop, packed)
+        tok = self.token_logprobs(hL, sb, save, packed)
         out = self._buf("seq_lp", (sb.Bq,), F32)
         hip.seq_reduce(tok, sb.seq_of_row, sb.n_rows, sb.Bq, sb.counts, 1 if reduce == "mean" else 0, out)
         if save:
@@ -806,7 +905,9 @@ class CaptionDecoderEngine:
         sb: SeqBatch = s["sb"]
         a = self.arch.gpt
         H, Pd, Bq, S, Mc = a.hidden, self.arch.proj_dim, sb.Bq, sb.S, sb.n_rows
-        M = Bq * S
+        pack: Optional[RowPack] = s.get("pack")
+        M = pack.Mp if pack is not None else Bq * S
+        cu, rows = (pack.cu, pack.row_ids) if pack is not None else (None, None)
         ws = self.ws
         rs = self._buf("row_scale", (Mc,), F32)
         # d tok_lp / d logits = onehot - softmax; the DLOGITS epilogue computes the cross-entropy form
@@ -829,8 +930,9 @@ class CaptionDecoderEngine:
         g_bf = self.trunk._buf("gbf_top", (M, H), BF16, zero=True)
         nb = hip.layernorm_bwd_blocks(Mc)
         part = ws.get("ln_part_f", (2, nb, H), F32)
-        hip.layernorm_bwd(s["hL"], Mc, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dhf, row_map=sb.row_map,
-                          dx_bf16=g_bf, part=part, drop_dx=self.trunk.top_drop())
+        hip.layernorm_bwd(s["hL"], Mc, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dhf,
+                          row_map=sb.row_map_packed if pack is not None else sb.row_map, dx_bf16=g_bf, part=part,
+                          drop_dx=self.trunk.top_drop(), drop_rows=rows)
         _ln_param_grads(part, nb, H, self.trunk.lnf_w.g, self.trunk.lnf_b.g)
         g0 = self.trunk.backward(g, g_bf)
         # embedding + attention_norm + 1-key cross-attention
@@ -843,7 +945,7 @@ class CaptionDecoderEngine:
         dvv = self._buf("dvv", (Bq, H), BF16)
         if drop is None:
             hip.embed_bwd(g0, sb.ids, sb.mask, Bq, S, H, self.wte.g, self.wpe.g, wte=self.wte.w, attended=s["att"],
-                          gamma=self.anw.w, mean=s["m0"], rstd=s["r0"], dattended=datt, part=parte)
+                          gamma=self.anw.w, mean=s["m0"], rstd=s["r0"], dattended=datt, part=parte, cu=cu)
             _ln_param_grads(parte, nbe, H, self.anw.g, self.anb.g)
             datt_bf = self._buf("datt_bf", (Bq, H), BF16)
             hip.cast_bf16(datt, datt_bf, Bq * H)
@@ -855,7 +957,7 @@ class CaptionDecoderEngine:
             dU = self._buf("dU", (Bq, XH, H), F32, zero=True)
             hip.embed_bwd(g0, sb.ids, sb.mask, Bq, S, H, self.wte.g, self.wpe.g, wte=self.wte.w, attended=self.ob.w,
                           att_stride=0, gamma=self.anw.w, mean=s["m0"], rstd=s["r0"], dattended=datt, part=parte,
-                          U=s["U"], dU=dU, xheads=XH, drop_x=drop(0, KIND_XATTN), drop_e=drop(0, KIND_EMBD))
+                          U=s["U"], dU=dU, xheads=XH, drop_x=drop(0, KIND_XATTN), drop_e=drop(0, KIND_EMBD), cu=cu)
             _ln_param_grads(parte, nbe, H, self.anw.g, self.anb.g)
             _bias_grad(ws, Bq, H, H, self.ob.g, x_f32=datt)        # d b_o = sum over rows of d e
             dU_bf = self._buf("dU_bf", (Bq, XH, H), BF16)
@@ -896,47 +998,58 @@ class TextTowerEngine:
     def _buf(self, name, shape, dtype, zero=False):
         return self.ws.get(f"{self.tag}.{name}", shape, dtype, zero)
 
-    def forward(self, ids: torch.Tensor, mask: torch.Tensor, save: bool, drop=None, head_drop=None):
-        """ids int64 [B,S], mask int32 [B,S] (device) -> (features [B,S,H] f32, pooled [B,H] f32, emb [B,P] f32)."""
+    def forward(self, ids: torch.Tensor, mask: torch.Tensor, save: bool, drop=None, head_drop=None,
+                pack: Optional[RowPack] = None):
+        """ids int64 [B,S], mask int32 [B,S] (device) -> (features [B,S,H] f32, pooled [B,H] f32, emb [B,P] f32).
+        ``pack`` (the training steps): the tower runs on the packed rows of the real tokens only; ``features`` are then
+        the packed rows [pack.Mp, H] (the padded [B,S,H] surface of ``text_features`` is the un-packed call's)."""
         a = self.arch.gpt
         B, S = ids.shape
-        H, M = a.hidden, B * S
+        H = a.hidden
+        M = pack.Mp if pack is not None else B * S
+        cu = pack.cu if pack is not None else None
+        pk = dict(row_ids=pack.row_ids, n_rows=M) if pack is not None else {}
         h0 = self._buf("h0", (M, H), F32)
-        hip.embed_fwd(ids, B, S, H, self.wte.w, self.wpe.w, h0, drop_e=drop(0, KIND_EMBD) if drop is not None else None)
-        hL = self.trunk.forward(h0, mask, B, S, save and self.seg.grad is not None, drop)
+        hip.embed_fwd(ids, B, S, H, self.wte.w, self.wpe.w, h0, drop_e=drop(0, KIND_EMBD) if drop is not None else None,
+                      **pk)
+        hL = self.trunk.forward(h0, mask, B, S, save and self.seg.grad is not None, drop, pack=pack)
         feats = self._buf("feats", (M, H), F32)
         mf, rf = self._buf("mf", (M,), F32), self._buf("rf", (M,), F32)
         hip.layernorm_fwd(hL, M, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_f32=feats, mean=mf, rstd=rf)
         pooled = self._buf("pooled", (B, H), F32)
-        hip.masked_mean_fwd(feats, mask, B, S, H, pooled)
+        hip.masked_mean_fwd(feats, mask, B, S, H, pooled, cu=cu)
         pooled_bf = self._buf("pooled_bf", (B, H), BF16)
         hip.cast_bf16(pooled, pooled_bf, B * H)
         emb = self.head.forward(pooled_bf, B, save, head_drop)
         if save:
-            self.saved = dict(ids=ids, mask=mask, hL=hL, mf=mf, rf=rf, B=B, S=S, drop=drop)
-        return feats.view(B, S, H), pooled, emb
+            self.saved = dict(ids=ids, mask=mask, hL=hL, mf=mf, rf=rf, B=B, S=S, drop=drop, pack=pack)
+        return (feats if pack is not None else feats.view(B, S, H)), pooled, emb
 
     def backward(self, demb: torch.Tensor) -> None:
         s, a, ws = self.saved, self.arch.gpt, self.ws
         B, S, H = s["B"], s["S"], a.hidden
-        M = B * S
+        pack: Optional[RowPack] = s.get("pack")
+        M = pack.Mp if pack is not None else B * S
+        cu, rows = (pack.cu, pack.row_ids) if pack is not None else (None, None)
         if self.seg.grad is None:      # freeze_text_backbone=True (reference model.py:354-368): only the head trains
             self.head.backward(demb, need_dx=False)
             return
         dpooled = self.head.backward(demb, need_dx=True)
         dfeats = self._buf("dfeats", (M, H), F32)
-        hip.masked_mean_bwd(dpooled, s["mask"], B, S, H, dfeats)
+        hip.masked_mean_bwd(dpooled, s["mask"], B, S, H, dfeats, cu=cu)
+        if pack is not None and pack.Mp > pack.n:
+            dfeats[pack.n:].zero_()    # filler rows: zero gradient
         g = self.trunk._buf("g_top", (M, H), F32)
         g_bf = self.trunk._buf("gbf_top", (M, H), BF16)
         nb = hip.layernorm_bwd_blocks(M)
         part = ws.get("ln_part_f", (2, nb, H), F32)
         hip.layernorm_bwd(s["hL"], M, H, self.trunk.lnf_w.w, s["mf"], s["rf"], g, dy_f32=dfeats, dx_bf16=g_bf, part=part,
-                          drop_dx=self.trunk.top_drop())
+                          drop_dx=self.trunk.top_drop(), drop_rows=rows)
         _ln_param_grads(part, nb, H, self.trunk.lnf_w.g, self.trunk.lnf_b.g)
         g0 = self.trunk.backward(g, g_bf)
         drop = s["drop"]
         hip.embed_bwd(g0, s["ids"], s["mask"], B, S, H, self.wte.g, self.wpe.g,
-                      drop_e=drop(0, KIND_EMBD) if drop is not None else None)
+                      drop_e=drop(0, KIND_EMBD) if drop is not None else None, cu=cu)
 
 
 # ------------------------------------------------------------------------------------------ NT-Xent (Stage 1 loss)

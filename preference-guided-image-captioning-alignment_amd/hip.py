@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("out_cols", _i32),
         ("drop_seed", C.c_uint32), ("drop_threshold", C.c_uint32), ("drop_scale", _f32),
         ("colsum_part", _vp), ("ld_colsum", _i32),
+        ("drop_rows", _vp),
     ]
 
 
@@ -52,17 +53,17 @@ _SIGS = {
     "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_layernorm_bwd_blocks": [_i32],
-    "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pgca_layernorm_bwd": [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "pgca_colsum_finish": [_vp, _i32, _i32, _vp, _i32, _vp],
     "pgca_colsum_finish4": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp],
     "pgca_colsum_blocks": [_i32],
     "pgca_colsum": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
-    "pgca_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, C.c_uint32, C.c_uint32, _f32, _vp],
-    "pgca_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, C.c_uint32, C.c_uint32, _f32, _vp],
+    "pgca_attention_fwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, C.c_uint32, C.c_uint32, _f32, _vp, _vp],
+    "pgca_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, C.c_uint32, C.c_uint32, _f32, _vp, _vp],
     "pgca_embed_fwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp,
-                       _vp],
+                       _vp, _i32, _vp],
     "pgca_embed_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp,
-                       _i32, _vp, _vp, _vp],
+                       _i32, _vp, _vp, _vp, _vp],
     "pgca_embed_bwd_blocks": [_i32, _i32],
     "pgca_patchify": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pgca_image_preprocess": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _f32,
@@ -75,8 +76,9 @@ _SIGS = {
     "pgca_dpo_loss": [_vp, _vp, _vp, _vp, _i32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_row_scale": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "pgca_seq_batch_prepare": [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pgca_masked_mean_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
-    "pgca_masked_mean_bwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "pgca_seq_pack_prepare": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pgca_masked_mean_fwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
+    "pgca_masked_mean_bwd": [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp],
     "pgca_l2norm_fwd": [_vp, _i32, _i32, _vp, _vp, _vp],
     "pgca_l2norm_bwd": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
     "pgca_ntxent_loss": [_vp, _vp, _vp, _i32, _i32, _vp, _vp],
@@ -93,7 +95,7 @@ _SIGS = {
     "pgca_gather_rows_bf16": [_vp, _vp, _i32, _i32, _vp, _vp],
 }
 EXPORTS = ["pgca_version", "pgca_last_error", "pgca_sizeof_gemm_args"] + list(_SIGS)
-ABI_VERSION = 201  # include/pgca_hip.h PGCA_ABI_VERSION
+ABI_VERSION = 300  # include/pgca_hip.h PGCA_ABI_VERSION
 
 _lib = None
 
@@ -146,7 +148,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
          aux_out: torch.Tensor = None, aux_in: torch.Tensor = None, ld_aux: int = None,
          targets: torch.Tensor = None, stat_max: torch.Tensor = None, stat_sum: torch.Tensor = None, stat_ld: int = 0,
          target_val: torch.Tensor = None, row_lse: torch.Tensor = None, row_scale: torch.Tensor = None,
-         out_cols: int = 0, drop=None, colsum_part: torch.Tensor = None) -> None:
+         out_cols: int = 0, drop=None, colsum_part: torch.Tensor = None, drop_rows: torch.Tensor = None) -> None:
     a = GemmArgs()
     a.A, a.B = A.data_ptr(), B.data_ptr()
     a.M, a.N, a.K = M, N, K
@@ -164,6 +166,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, M: int, N: int, K: int, layout: int, 
     a.out_cols = out_cols
     if drop is not None:
         a.drop_seed, a.drop_threshold, a.drop_scale = drop
+        a.drop_rows = _p(drop_rows)
     if colsum_part is not None:
         a.colsum_part, a.ld_colsum = colsum_part.data_ptr(), colsum_part.shape[1]
     probe = gemm_probe
@@ -225,10 +228,10 @@ def layernorm_bwd_blocks(M: int) -> int:
 
 
 def layernorm_bwd(x, M, H, gamma, mean, rstd, dx_out, *, dy_bf16=None, dy_f32=None, row_map=None, add_to=None,
-                  dx_bf16=None, part=None, part_extra=None, drop_add=None, drop_dx=None):
+                  dx_bf16=None, part=None, part_extra=None, drop_add=None, drop_dx=None, drop_rows=None):
     _check(load().pgca_layernorm_bwd(_p(dy_bf16), _p(dy_f32), _p(x), _p(row_map), M, H, _p(gamma), _p(mean),
                                      _p(rstd), _p(add_to), _p(dx_out), _p(dx_bf16), _p(part), _p(part_extra),
-                                     _drop_words(drop_add), _drop_words(drop_dx), _stream()),
+                                     _drop_words(drop_add), _drop_words(drop_dx), _p(drop_rows), _stream()),
            "pgca_layernorm_bwd")
 
 
@@ -264,24 +267,28 @@ def _drop_words(d):
     return C.cast(arr, C.c_void_p)
 
 
-def attention_fwd(qkv, key_mask, B, S, heads, causal, out, lse=None, drop=None):
+def attention_fwd(qkv, key_mask, B, S, heads, causal, out, lse=None, drop=None, cu=None):
+    """``cu`` (int32 [B+1]): packed rows - sequence b is rows cu[b]..cu[b+1]-1; S stays the padded length."""
     d = drop or _NODROP
     _check(load().pgca_attention_fwd(_p(qkv), _p(key_mask), B, S, heads, 1 if causal else 0, _p(out), _p(lse),
-                                     d[0], d[1], d[2], _stream()), "pgca_attention_fwd")
+                                     d[0], d[1], d[2], _p(cu), _stream()), "pgca_attention_fwd")
 
 
-def attention_bwd(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, drop=None):
+def attention_bwd(qkv, out, dout, lse, key_mask, B, S, heads, causal, dqkv, drop=None, cu=None):
     d = drop or _NODROP
     _check(load().pgca_attention_bwd(_p(qkv), _p(out), _p(dout), _p(lse), _p(key_mask), B, S, heads,
-                                     1 if causal else 0, _p(dqkv), d[0], d[1], d[2], _stream()), "pgca_attention_bwd")
+                                     1 if causal else 0, _p(dqkv), d[0], d[1], d[2], _p(cu), _stream()),
+           "pgca_attention_bwd")
 
 
 # --------------------------------------------------------------------------- embeddings / ViT input
 def embed_fwd(ids, B, S, H, wte, wpe, h0, attended=None, gamma=None, beta=None, eps=1e-5, mean=None, rstd=None,
-              att_stride=None, U=None, xheads=0, drop_x=None, drop_e=None):
+              att_stride=None, U=None, xheads=0, drop_x=None, drop_e=None, row_ids=None, n_rows=0):
+    """``row_ids`` (int32 [n_rows]): packed rows - output row r is padded position row_ids[r] (< 0: zero filler)."""
     _check(load().pgca_embed_fwd(_p(ids), B, S, H, _p(wte), _p(wpe), _p(attended), _p(gamma), _p(beta), eps, _p(h0),
                                  _p(mean), _p(rstd), H if att_stride is None else att_stride, _p(U), xheads,
-                                 _drop_words(drop_x), _drop_words(drop_e), _stream()), "pgca_embed_fwd")
+                                 _drop_words(drop_x), _drop_words(drop_e), _p(row_ids), n_rows, _stream()),
+           "pgca_embed_fwd")
 
 
 def embed_bwd_blocks(B: int, S: int) -> int:
@@ -289,11 +296,12 @@ def embed_bwd_blocks(B: int, S: int) -> int:
 
 
 def embed_bwd(g, ids, row_mask, B, S, H, dwte, dwpe, wte=None, attended=None, gamma=None, mean=None, rstd=None,
-              dattended=None, part=None, att_stride=None, U=None, dU=None, xheads=0, drop_x=None, drop_e=None):
+              dattended=None, part=None, att_stride=None, U=None, dU=None, xheads=0, drop_x=None, drop_e=None,
+              cu=None):
     _check(load().pgca_embed_bwd(_p(g), _p(ids), _p(row_mask), B, S, H, _p(wte), _p(attended), _p(gamma), _p(mean),
                                  _p(rstd), _p(dwte), _p(dwpe), _p(dattended), _p(part),
                                  H if att_stride is None else att_stride, _p(U), _p(dU), xheads, _drop_words(drop_x),
-                                 _drop_words(drop_e), _stream()), "pgca_embed_bwd")
+                                 _drop_words(drop_e), _p(cu), _stream()), "pgca_embed_bwd")
 
 
 def patchify(pixels, B, image, patch, out_bf16, ld_out=None):
@@ -344,17 +352,23 @@ def seq_batch_prepare(ids, mask, Bq, S, counts, mask32, row_map, targets, seq_of
            "pgca_seq_batch_prepare")
 
 
+def seq_pack_prepare(mask32, Bq, S, pad_to, lens, cu, row_ids, n_packed, counts=None, row_map=None):
+    _check(load().pgca_seq_pack_prepare(_p(mask32), Bq, S, pad_to, _p(lens), _p(cu), _p(row_ids), _p(n_packed),
+                                        _p(counts), _p(row_map), _stream()), "pgca_seq_pack_prepare")
+
+
 def row_scale(dseq, seq_of_row, seq_count, nrows, mode, out):
     _check(load().pgca_row_scale(_p(dseq), _p(seq_of_row), _p(seq_count), nrows, mode, _p(out), _stream()),
            "pgca_row_scale")
 
 
-def masked_mean_fwd(feats, mask, B, S, H, pooled):
-    _check(load().pgca_masked_mean_fwd(_p(feats), _p(mask), B, S, H, _p(pooled), _stream()), "pgca_masked_mean_fwd")
+def masked_mean_fwd(feats, mask, B, S, H, pooled, cu=None):
+    _check(load().pgca_masked_mean_fwd(_p(feats), _p(mask), B, S, H, _p(pooled), _p(cu), _stream()),
+           "pgca_masked_mean_fwd")
 
 
-def masked_mean_bwd(dpooled, mask, B, S, H, dfeats):
-    _check(load().pgca_masked_mean_bwd(_p(dpooled), _p(mask), B, S, H, _p(dfeats), _stream()),
+def masked_mean_bwd(dpooled, mask, B, S, H, dfeats, cu=None):
+    _check(load().pgca_masked_mean_bwd(_p(dpooled), _p(mask), B, S, H, _p(dfeats), _p(cu), _stream()),
            "pgca_masked_mean_bwd")
 
 

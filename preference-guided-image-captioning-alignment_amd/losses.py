@@ -66,7 +66,7 @@ def _token_logprobs(logits: torch.Tensor, labels: torch.Tensor, mask: Optional[t
     B, S, V = logits.shape
     if mask is None:
         mask = torch.ones_like(labels)
-    sb = make_seq_batch(labels, mask, dev)
+    sb = make_seq_batch(labels, mask, dev, pack=False)
     lg = logits.detach().to(F32).contiguous()
     tok = torch.empty(sb.n_rows, dtype=F32, device=dev)
     hip.logits_logprob(lg, V, V, sb.row_map, sb.targets, sb.n_rows, tok)

@@ -193,12 +193,12 @@ class CaptionDecoder:
             return DecoderOutput(logits=self.engine.next_token_logits(pv, empty)[:, None, :].contiguous(), loss=None)
         if attention_mask is None:
             attention_mask = torch.ones_like(input_ids)
-        sb = make_seq_batch(input_ids, attention_mask, dev)
+        sb = make_seq_batch(input_ids, attention_mask, dev, pack=False)
         logits = self.engine.logits(vision_features.to(dev, F32).contiguous(), sb)
         loss = None
         if labels is not None:  # HF ForCausalLMLoss: mean CE over all shifted positions (modeling_gpt2.py:700-716)
             B, S, V = logits.shape
-            full = make_seq_batch(labels, torch.ones_like(labels), dev)
+            full = make_seq_batch(labels, torch.ones_like(labels), dev, pack=False)
             tok = torch.empty(full.n_rows, dtype=F32, device=dev)
             hip.logits_logprob(logits, V, V, full.row_map, full.targets, full.n_rows, tok)
             loss = -tok.mean()

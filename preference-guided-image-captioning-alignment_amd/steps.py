@@ -17,8 +17,8 @@ import torch
 
 from . import hip
 from .engine import (BF16, F32, I32, I64, KIND_HEAD, TOWER_DECODER, TOWER_TEXT, TOWER_THEAD, TOWER_VHEAD,
-                     CaptionDecoderEngine, DropoutPlan, NTXentEngine, ProjHead, SeqBatch, TextTowerEngine, VisionTower,
-                     Workspace, make_seq_batch)
+                     CaptionDecoderEngine, DropoutPlan, NTXentEngine, ProjHead, RowPack, SeqBatch, TextTowerEngine,
+                     VisionTower, Workspace, make_row_pack, make_seq_batch)
 from .params import ParamStore, Segment
 
 
@@ -119,7 +119,7 @@ class DPOStep:
     def __init__(self, store: ParamStore, ws: Workspace, vit: VisionTower, vhead: ProjHead,
                  dec: CaptionDecoderEngine, beta: float = 0.1, reference_free: bool = False,
                  label_smoothing: float = 0.0, reduce: Optional[str] = None, ref: Optional[ReferencePolicy] = None,
-                 ref_side_stream: bool = False, dropout: Optional[DropoutPlan] = None):
+                 ref_side_stream: bool = False, dropout: Optional[DropoutPlan] = None, packed: bool = True):
         self.store, self.ws, self.vit, self.vhead, self.dec = store, ws, vit, vhead, dec
         self.beta, self.reference_free, self.ls = float(beta), bool(reference_free), float(label_smoothing)
         # trainer parity: 2-forward == PreferenceLoss (length-mean); 4-forward == DPOPreferenceLoss (length-sum)
@@ -134,6 +134,9 @@ class DPOStep:
         self.ref_side_stream = bool(ref_side_stream)
         # train-mode dropout of the policy (the frozen reference policy always runs without dropout)
         self.dropout = dropout if dropout is not None else DropoutPlan(0.0)
+        # both decoder trunks (policy and reference) run on the rows of the real tokens only (engine.RowPack); False
+        # computes every padded position like the reference does (same scored log-probs, loss and gradients)
+        self.packed = bool(packed)
 
     @staticmethod
     def prepare(batch: dict, device) -> dict:
@@ -158,6 +161,7 @@ class DPOStep:
         emb2[:B].copy_(emb)
         emb2[B:].copy_(emb)
         ref_lp = None
+        packed = self.packed and sb.pack is not None
         if not self.reference_free:
             # the frozen reference policy runs on its own HIP stream, concurrently with the policy forward:
             # the two kernel sequences are independent, so one's store-bound epilogues and tile tails are
@@ -174,8 +178,8 @@ class DPOStep:
                 remb2 = self.ws.get("dpo.remb2", (2 * B, P), F32)
                 remb2[:B].copy_(remb)
                 remb2[B:].copy_(remb)
-                ref_lp = self.ref.dec.sequence_logprobs(remb2, sb, self.reduce, False)
-        pol = self.dec.sequence_logprobs(emb2, sb, self.reduce, save, plan.bind(TOWER_DECODER))
+                ref_lp = self.ref.dec.sequence_logprobs(remb2, sb, self.reduce, False, packed=packed)
+        pol = self.dec.sequence_logprobs(emb2, sb, self.reduce, save, plan.bind(TOWER_DECODER), packed=packed)
         if ref_lp is not None and self._ref_stream is not torch.cuda.current_stream():
             torch.cuda.current_stream().wait_stream(self._ref_stream)
         return pol, ref_lp
@@ -213,33 +217,44 @@ class ContrastiveStep:
     ``rank`` / ``world`` for global negatives; without it negatives are local (as the reference)."""
 
     def __init__(self, store: ParamStore, ws: Workspace, vit: VisionTower, vhead: ProjHead, text: TextTowerEngine,
-                 temperature: float, dp=None, global_negatives: bool = False, dropout: Optional[DropoutPlan] = None):
+                 temperature: float, dp=None, global_negatives: bool = False, dropout: Optional[DropoutPlan] = None,
+                 packed: bool = True):
         self.store, self.ws, self.vit, self.vhead, self.text = store, ws, vit, vhead, text
+        self.packed = bool(packed)   # text tower on the real tokens' rows only (engine.RowPack)
         self.dropout = dropout if dropout is not None else DropoutPlan(0.0)
         self.ntx = NTXentEngine(ws, store.arch.proj_dim, temperature)
         self.dp = dp if (dp is not None and global_negatives and dp.world > 1) else None
 
     @staticmethod
     def prepare(batch: dict, device) -> dict:
+        mask = (batch["caption_mask"] != 0).to(I32).to(device, non_blocking=True).contiguous()
         return {"image": batch["image"].to(device, F32, non_blocking=True),
                 "ids": batch["caption_ids"].to(device, I64, non_blocking=True),
-                "mask": (batch["caption_mask"] != 0).to(I32).to(device, non_blocking=True)}
+                "mask": mask, "pack": make_row_pack(mask)}
 
-    def forward(self, images, ids, mask, save: bool = True):
+    def _pack(self, mask, pack: Optional[RowPack]) -> Optional[RowPack]:
+        if not self.packed:
+            return None
+        return pack if pack is not None else make_row_pack(mask.contiguous())   # (one host wait; prepare() avoids it)
+
+    def forward(self, images, ids, mask, save: bool = True, pack: Optional[RowPack] = None):
+        """``pack`` (``prepare()['pack']``): packed row layout of ``mask``; the text tower then computes the real tokens
+        only and ``text_features`` are its packed rows (the training steps do not read them)."""
         B = images.shape[0]
         feats_v, _, pooled_bf = self.vit.forward(images, save)
         plan = self.dropout
         plan.active = bool(save)
         iemb = self.vhead.forward(pooled_bf, B, save, plan.site(TOWER_VHEAD, 0, KIND_HEAD))
-        feats_t, _, temb = self.text.forward(ids, mask, save, plan.bind(TOWER_TEXT), plan.site(TOWER_THEAD, 0, KIND_HEAD))
+        feats_t, _, temb = self.text.forward(ids, mask, save, plan.bind(TOWER_TEXT), plan.site(TOWER_THEAD, 0, KIND_HEAD),
+                                             pack=pack)
         img_n, in_norm = self.ntx.normalize(iemb, "i")
         txt_n, tn_norm = self.ntx.normalize(temb, "t")
         return dict(image_embeddings=img_n, text_embeddings=txt_n, vision_features=feats_v, text_features=feats_t,
                     _in=in_norm, _tn=tn_norm)
 
-    def loss_and_grads(self, images, ids, mask, loss_scale: float = 1.0) -> torch.Tensor:
+    def loss_and_grads(self, images, ids, mask, loss_scale: float = 1.0, pack: Optional[RowPack] = None) -> torch.Tensor:
         B = images.shape[0]
-        o = self.forward(images, ids, mask, True)
+        o = self.forward(images, ids, mask, True, self._pack(mask, pack))
         self.dropout.step += 1
         img_n, txt_n = o["image_embeddings"], o["text_embeddings"]
         if self.dp is None:
@@ -265,7 +280,7 @@ class ContrastiveStep:
         return loss
 
     @torch.no_grad()
-    def loss_only(self, images, ids, mask) -> torch.Tensor:
-        o = self.forward(images, ids, mask, False)
+    def loss_only(self, images, ids, mask, pack: Optional[RowPack] = None) -> torch.Tensor:
+        o = self.forward(images, ids, mask, False, self._pack(mask, pack))
         loss, _, _ = self.ntx.forward(o["image_embeddings"], o["text_embeddings"])
         return loss

@@ -186,10 +186,10 @@ class PreferenceGuidedTrainer:
         extra = [s for s in opt.segments if s is not reducer.seg]
 
         def micro(p, scale):
-            return step.loss_and_grads(p["image"], p["ids"], p["mask"], loss_scale=scale)
+            return step.loss_and_grads(p["image"], p["ids"], p["mask"], loss_scale=scale, pack=p.get("pack"))
 
         def val(p):
-            return step.loss_only(p["image"], p["ids"], p["mask"])
+            return step.loss_only(p["image"], p["ids"], p["mask"], pack=p.get("pack"))
 
         return self._train_loop(1, sc, opt, self.train_loader_stage1, self.val_loader_stage1, ContrastiveStep.prepare,
                                 micro, val, reducer, extra)

@@ -59,5 +59,5 @@ def test_host_side_argument_validation_needs_no_gpu(lib):
     a = hip.GemmArgs()
     assert lib.pgca_gemm_bf16(ctypes.byref(a), None) == -1
     assert b"null operand" in lib.pgca_last_error()
-    assert lib.pgca_attention_fwd(None, None, 1, 128, 1, 1, None, None, 0, 0, 1.0, None) == -1
+    assert lib.pgca_attention_fwd(None, None, 1, 128, 1, 1, None, None, 0, 0, 1.0, None, None) == -1
     assert lib.pgca_sqnorm_blocks(1) == 1 and lib.pgca_sqnorm_blocks(16384 * 3 + 1) == 4
