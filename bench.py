@@ -138,14 +138,84 @@ def pmc_from_profile(pairs_per_gpu: int, kernel_substr: str):
     return None
 
 
+def self_launch(n: int, argv, timeout_s: float) -> int:
+    """``python bench.py --gpus N`` started as ONE plain process (how the driver starts ``--gpus 1``): spawn the N ranks
+    here, as fresh children of a parent that has not touched the GPU (no HIP call, no ``torch.cuda.*``) - one
+    ``torch.distributed.run`` child that starts one rank per GPU, the launch the reference gets from Accelerate
+    (reference scripts/train.py:317-322).  Rank 0's single JSON line is forwarded on stdout; the exit code is non-zero if
+    any rank fails or the job exceeds ``timeout_s``."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    log(f"self-launch: {n} ranks via torch.distributed.run on 127.0.0.1:{port}")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)      # exactly the process group started above
+        proc.wait()
+        print(f"[bench] self-launched job exceeded {timeout_s:.0f} s and was killed", file=sys.stderr, flush=True)
+        return 124
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if proc.returncode != 0:
+        print(f"[bench] a rank failed (torch.distributed.run exit code {proc.returncode})", file=sys.stderr, flush=True)
+        return proc.returncode or 1
+    if len(lines) != 1:
+        print(f"[bench] expected ONE result line from rank 0, got {len(lines)}", file=sys.stderr, flush=True)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
+def dry_launch(args) -> None:
+    """``--dry-launch``: every rank joins the process group (RCCL, or gloo under PGCA_BENCH_BACKEND=gloo), proves the group
+    with one all-reduce and rank 0 prints a result-shaped line - the launcher, the rendezvous and the rc propagation
+    without a model or a GPU kernel (tests/test_bench_launch_cpu.py)."""
+    import torch.distributed as dist
+    backend = os.environ.get("PGCA_BENCH_BACKEND", "nccl")
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("PGCA_BENCH_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+        dist.init_process_group(backend=backend)
+    if args.dry_fail_rank == rank:
+        raise SystemExit(3)
+    t = torch.ones(1, device="cuda" if backend == "nccl" and world > 1 else "cpu")
+    if world > 1:
+        dist.all_reduce(t)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry launch (no model, no kernel)", "value": 0.0, "unit": "pairs/s",
+                          "n_gpus": args.gpus, "dry_launch": True, "ranks_summed": int(t.item()),
+                          "process_group": {"world_size": dist.get_world_size() if world > 1 else 1,
+                                            "backend": dist.get_backend() if world > 1 else "none"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher rehearsal: ranks rendezvous, all-reduce once, rank 0 prints a result-shaped line")
+    ap.add_argument("--dry-fail-rank", type=int, default=-1, help="--dry-launch: this rank exits with code 3")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launched job limit in seconds")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=256,
-                    help="preference pairs per GPU per optimizer step (round 1 ran 128; 256 uses ~80 of the 288 GB and "
-                         "amortises per-launch tails: +5 %% pairs/s)")
+    ap.add_argument("--pairs-per-gpu", type=int, default=512,
+                    help="preference pairs per GPU per optimizer step (rounds 1-2 ran 128 / 256 on padded rows; with packed "
+                         "rows 512 pairs are ~75 k token rows per GEMM and ~90 of the 288 GB: +5 %% pairs/s over 256)")
+    ap.add_argument("--padded", action="store_true",
+                    help="A/B: run the trunks on all B x S padded positions like the reference (round-2 behaviour) instead "
+                         "of the packed rows of the real tokens")
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--vision-model", default="openai/clip-vit-base-patch32")
     ap.add_argument("--text-model", default="gpt2-medium")
@@ -174,6 +244,12 @@ def main():
                          "(global negatives over the ranks when N > 1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process becomes the launcher (nothing below has touched the GPU)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))
+    if args.dry_launch:
+        return dry_launch(args)
+
     from pgca_amd import hip
     from pgca_amd.arch import make_arch
     from pgca_amd.dist import DataParallel, OverlappedTrunkReducer
@@ -184,7 +260,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
     # rehearsal hooks (one-GPU box): PGCA_BENCH_DEVICE pins every rank to one card, PGCA_BENCH_BACKEND=gloo
     # swaps the transport; the driver's runs use neither (one rank per GPU over RCCL)
     dev_index = int(os.environ.get("PGCA_BENCH_DEVICE", local_rank))
@@ -207,7 +283,7 @@ def main():
         ref = None
         step = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
                                model.text_encoder.engine, temperature=0.5, dp=dp, global_negatives=True,
-                               dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
+                               dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank), packed=not args.padded)
         segs = [model.store.segments["vision_head"], model.store.segments["text_head"],
                 model.store.segments["text_tower"]]
         trunk = model.text_encoder.engine.trunk
@@ -215,7 +291,8 @@ def main():
         ref = None if args.reference_free else ReferencePolicy(model.store, model.ws)
         step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
                        model.caption_decoder.engine, beta=beta, reference_free=args.reference_free, ref=ref,
-                       ref_side_stream=args.ref_side_stream, dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank))
+                       ref_side_stream=args.ref_side_stream, dropout=DropoutPlan(args.dropout, base_seed=42 + dp.rank),
+                       packed=not args.padded)
         segs = [model.store.segments["vision_head"], model.store.segments["decoder"]]
         trunk = model.caption_decoder.engine.trunk
     if args.trainable_vision:
@@ -251,7 +328,7 @@ def main():
         batches = None
     else:
         batches = [prep(r, dev) for r in raw]
-        del raw
+
     probe = GemmProbe(hip.NN)
     if not args.no_probe and dp.rank == 0:
         hip.gemm_probe = probe
@@ -310,6 +387,27 @@ def main():
             flop_pair = 3 * (24 * g.hidden ** 2 * g.layers + 4 * S * g.hidden * g.layers) * S + vit_fwd
         if args.trainable_vision:
             flop_pair += 2 * vit_fwd     # the tower's backward
+        # EXECUTED FLOPs per pair: the same formulas on the rows the kernels were actually launched on - the packed token
+        # rows (incl. filler) for the trunk, l x l attention per sequence, and the scored rows only for the LM head
+        # (forward x 2 policies; backward = logits recompute + data gradient + weight gradient)
+        import numpy as _np
+        ex_rows, ex_att, ex_lm = [], [], []
+        for r in raw:
+            keys = ("caption_mask",) if stage1 else ("preferred_mask", "rejected_mask")
+            m = _np.concatenate([r[k].numpy() for k in keys])
+            lens = _np.array([0 if not x.any() else int(_np.nonzero(x)[0].max()) + 1 for x in m])
+            n = int(lens.sum())
+            ex_rows.append(m.size if args.padded else (n + 63) // 64 * 64)
+            ex_att.append(float(m.shape[0]) * S * S if args.padded else float((lens.astype(_np.float64) ** 2).sum()))
+            ex_lm.append(int((m[:, 1:] != 0).sum()))
+        rows_b, att_b, lm_b = (float(_np.mean(x)) for x in (ex_rows, ex_att, ex_lm))
+        trunk_tok = 24 * g.hidden ** 2 * g.layers
+        att_unit = 4 * g.hidden * g.layers
+        n_trunk = 3 if stage1 else (3 if args.reference_free else 4)    # fwd + 2 x bwd (+ reference fwd)
+        ex_step = n_trunk * (trunk_tok * rows_b + att_unit * att_b) + vit_fwd * B * (3 if args.trainable_vision else 1)
+        if not stage1:
+            ex_step += (4 if args.reference_free else 5) * 2 * g.hidden * arch.dec_vocab * lm_b
+        exec_pair = ex_step / B
         frozen = "trainable" if args.trainable_vision else "frozen"
         short = {"openai/clip-vit-base-patch32": "CLIP-ViT-B/32", "openai/clip-vit-base-patch16": "CLIP-ViT-B/16",
                  "openai/clip-vit-large-patch14": "CLIP-ViT-L/14", "gpt2": "GPT-2", "gpt2-medium": "GPT-2-M",
@@ -340,8 +438,15 @@ def main():
                                    "replayed in backward); reference policy in eval mode") if args.dropout > 0
                        else "identity (p=0)"},
             "algorithmic_gflop_per_pair": flop_pair / 1e9,
+            "executed_gflop_per_pair": exec_pair / 1e9,
+            "rows": ("all B x S padded positions" if args.padded else
+                     f"packed: {rows_b:.0f} of {len(raw[0]['image']) * (1 if stage1 else 2) * S} token rows per step"),
             "step_tflops_per_gpu": flop_pair * B / (dt / args.steps) / 1e12,
+            "executed_tflops_per_gpu": exec_pair * B / (dt / args.steps) / 1e12,
             "loss": loss_val, "grad_norm": st["grad_norm"], "opt_steps": st["step"],
+            # what the process group itself reports (N ranks over RCCL when the backend is nccl)
+            "process_group": {"world_size": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                              "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else "none"},
         }
         ps = probe.summary()
         if ps:
