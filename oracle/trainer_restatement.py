@@ -14,8 +14,10 @@
 * the cosine schedule advances ``world`` positions per optimiser step (scheduler.py:54-82).
 
 Only ``tests/`` import this module.  Parity pinning: the model / loss arithmetic underneath is
-``oracle/restatement.py``, pinned against the imported reference by ``tests/golden``; the loop itself is restated
-from the source text (the trainer imports mlflow, which this image lacks - SURVEY 8c).
+``oracle/restatement.py``, pinned against the imported reference by ``tests/golden``; the LOOP is pinned against a run of
+the reference's own ``_train_epoch_stage1`` / ``_train_epoch_stage2`` under a real ``accelerate.Accelerator``
+(``tests/golden/trainer_epoch.npz``, written by ``oracle/make_trainer_golden.py``: accumulation 2, a NaN micro-batch
+opening and one closing a group, a trailing partial group, two epochs) by ``tests/test_trainer_oracle_cpu.py``.
 """
 from __future__ import annotations
 
@@ -40,7 +42,7 @@ def run_epochs(sd: Dict[str, torch.Tensor], train: Sequence[str], batches: List[
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
     opt_step, sched_step, global_step = 0, 0, 0
-    losses, epoch_means, lrs = [], [], []
+    losses, epoch_means, lrs, lr_in_force = [], [], [], []
 
     def zero():
         for g in grads:
@@ -54,6 +56,8 @@ def run_epochs(sd: Dict[str, torch.Tensor], train: Sequence[str], batches: List[
             loss = loss_fn(sd, b)
             lv = float(loss.detach())
             losses.append(lv)
+            # what optimizer.param_groups[0]["lr"] reads during this micro-batch: the schedule at the current position
+            lr_in_force.append(R.cosine_warmup_lr(lr, sched_step, warmup, total_steps))
             if not math.isfinite(lv):                            # trainer.py:481-489 / 606-613
                 if boundary:
                     zero()
@@ -86,7 +90,7 @@ def run_epochs(sd: Dict[str, torch.Tensor], train: Sequence[str], batches: List[
             global_step += 1
         epoch_means.append(total / count if count else 0.0)
     return {"losses": losses, "epoch_means": epoch_means, "opt_steps": opt_step, "sched_step": sched_step,
-            "global_step": global_step, "lrs": lrs, "exp_avg": dict(zip(train, m)), "exp_avg_sq": dict(zip(train, v))}
+            "global_step": global_step, "lrs": lrs, "lr_in_force": lr_in_force, "exp_avg": dict(zip(train, m)), "exp_avg_sq": dict(zip(train, v))}
 
 
 def stage2_loss(arch, beta: float):

@@ -1,0 +1,257 @@
+"""Full-depth parity of the benchmarked configuration, and the pieces no depth-2 test reached.
+
+* config C2 AS BENCHMARKED - ViT-B/32 x 12 layers + GPT-2-Medium x 24 layers, S = 128, ragged right-padded captions,
+  packed rows: the Stage-2 4-forward DPO step (policy and reference log-probs, loss, 14 gradient tensors incl. the tied
+  ``wte``, the first and the last block) and the Stage-1 step (loss, text-tower and text-head gradients) against the
+  oracle restatement on identical weights / batch.  Reference: models/model.py:561-619 (decoder), :402-474 (text tower),
+  models/components.py:192-249,321-362 (DPO), models/model.py:984-1000 (NT-Xent).
+* config C5's Stage-1 half at ViT-L/14 + GPT-2-XL width (depth 2), followed by a Stage-2 step on the weights that
+  Stage-1 step left (the S1 -> S2 carry-over at real width).
+* the projection heads + NT-Xent backward on the SHIPPED initialisation, isolated from tower noise: the oracle is fed
+  the HIP towers' own pooled outputs (reference models/model.py:136-142,828-829,984-1000).
+
+Tolerances are SURVEY 8(d)'s, unchanged: per-sequence mean log-prob |d| <= 2e-2, loss |d| <= 5e-3, gradient cosine
+>= 0.99 (bf16 MFMA operands, f32 accumulation, f32 residual streams).  Measured at full depth: see the asserts' messages
+in gpurun logs / DESIGN.md section 2.
+"""
+import pytest
+import torch
+
+from oracle import restatement as R
+
+pytestmark = pytest.mark.gpu
+
+
+def cos(a, b):
+    a, b = a.double().flatten().cpu(), torch.as_tensor(b).double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def ragged(B, S, lens, gen):
+    ids = torch.randint(0, 50257, (B, S), generator=gen)
+    mask = (torch.arange(S)[None] < torch.tensor(lens)[:, None]).long()
+    return torch.where(mask.bool(), ids, torch.full_like(ids, 50257)), mask
+
+
+@pytest.fixture(scope="module")
+def full_c2():
+    from pgca_amd.arch import make_arch
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    arch = make_arch("openai/clip-vit-base-patch32", "gpt2-medium", 512)
+    assert arch.vit.layers == 12 and arch.gpt.layers == 24
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=arch, seed=2025, device="cuda:0")
+    return model, arch
+
+
+def test_full_depth_c2_stage2_four_forward(full_c2):
+    from pgca_amd.steps import DPOStep, ReferencePolicy
+    model, arch = full_c2
+    gen = torch.Generator().manual_seed(31)
+    B, S = 2, 128
+    img = torch.randn(B, 3, 224, 224, generator=gen)
+    ids, mask = ragged(2 * B, S, [128, 40, 77, 16], gen)
+    batch = {"image": img, "preferred_ids": ids[:B], "rejected_ids": ids[B:], "preferred_mask": mask[:B],
+             "rejected_mask": mask[B:]}
+    ref = ReferencePolicy(model.store, model.ws)
+    for seg in ref.store.segments.values():     # a reference policy that is not the policy (else every DPO logit is 0)
+        seg.fp32.mul_(1.01)
+        seg.ensure_bf16()
+    step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                   model.caption_decoder.engine, beta=0.1, reference_free=False, ref=ref)
+    p = DPOStep.prepare(batch, model.device)
+    assert p["seq"].pack is not None and p["seq"].pack.n == 128 + 40 + 77 + 16
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss = float(step.loss_and_grads(p["image"], p["seq"]))
+    pol = model.ws.bufs["pol.seq_lp"][:2 * B].cpu()
+    rlp = model.ws.bufs["ref.seq_lp"][:2 * B].cpu()
+    cnt = (mask[:, 1:] != 0).sum(1).float()
+    # ---- oracle, fp32 on the host
+    train = ("caption_decoder", "vision_encoder.projection")
+    sd = {k: v.detach().cpu().clone().requires_grad_(k.startswith(train))
+          for k, v in model.store.state_dict(aliases=False).items()}
+    sd_ref = {k: v.detach().cpu().clone() for k, v in sd.items()}
+    for k, v in ref.store.state_dict(aliases=False).items():
+        sd_ref[k] = v.detach().cpu().clone()
+
+    def lps(weights, grad):
+        with torch.set_grad_enabled(grad):
+            out = []
+            for sl in (slice(0, B), slice(B, 2 * B)):
+                lg = R.model_forward(weights, img, ids[sl], mask[sl], "generation", arch.vit.heads, arch.vit.patch,
+                                     arch.gpt.heads)["logits"]
+                out.append(R.sequence_logprob_sum(lg, ids[sl], mask[sl]))
+            return out
+    pw, pl = lps(sd, True)
+    rw, rl = lps(sd_ref, False)
+    ref_loss, _ = R.dpo_loss(pw, pl, rw, rl, beta=0.1)
+    ref_loss.backward()
+    want_pol, want_ref = torch.cat([pw, pl]).detach(), torch.cat([rw, rl])
+    d_pol = float(((pol - want_pol) / cnt).abs().max())
+    d_ref = float(((rlp - want_ref) / cnt).abs().max())
+    print(f"full depth C2 stage 2: per-token-mean log-prob |d| policy {d_pol:.2e} reference {d_ref:.2e}; "
+          f"loss {loss:.5f} vs {float(ref_loss):.5f}")
+    assert d_pol <= 2e-2 and d_ref <= 2e-2, (d_pol, d_ref)
+    assert abs(loss - float(ref_loss)) <= 5e-3, (loss, float(ref_loss))
+    dec = "caption_decoder.lm_model.transformer."
+    worst = 1.0
+    for name in (dec + "wte.weight", dec + "wpe.weight", dec + "h.0.attn.c_attn.weight", dec + "h.0.attn.c_attn.bias",
+                 dec + "h.0.mlp.c_fc.weight", dec + "h.0.ln_1.weight", dec + "h.11.attn.c_proj.weight",
+                 dec + "h.12.mlp.c_proj.weight", dec + "h.23.attn.c_attn.weight", dec + "h.23.mlp.c_fc.weight",
+                 dec + "h.23.mlp.c_proj.bias", dec + "h.23.ln_2.weight", dec + "ln_f.weight",
+                 "caption_decoder.vision_projection.0.weight", "caption_decoder.cross_attention.out_proj.weight",
+                 "caption_decoder.attention_norm.weight", "vision_encoder.projection.0.weight",
+                 "vision_encoder.projection.4.weight"):
+        c = cos(model.store.g(name), sd[name].grad)
+        worst = min(worst, c)
+        assert c >= 0.99, f"{name}: cosine {c}"
+    print(f"full depth C2 stage 2: worst gradient cosine {worst:.5f}")
+    # q/k rows of the collapsed cross-attention: exactly zero, as in the reference
+    H = arch.gpt.hidden
+    assert float(model.store.g("caption_decoder.cross_attention.in_proj_weight")[:2 * H].abs().max()) == 0.0
+
+
+def test_full_depth_c2_stage1(full_c2):
+    from pgca_amd.steps import ContrastiveStep
+    model, arch = full_c2
+    gen = torch.Generator().manual_seed(32)
+    B, S, tau = 4, 128, 0.5
+    img = torch.randn(B, 3, 224, 224, generator=gen)
+    ids, mask = ragged(B, S, [128, 40, 77, 16], gen)
+    step = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                           model.text_encoder.engine, temperature=tau)
+    p = ContrastiveStep.prepare({"image": img, "caption_ids": ids, "caption_mask": mask}, model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss = float(step.loss_and_grads(p["image"], p["ids"], p["mask"], pack=p["pack"]))
+    sd = {k: v.detach().cpu().clone().requires_grad_(k.startswith(("text_encoder", "vision_encoder.projection")))
+          for k, v in model.store.state_dict(aliases=False).items()}
+    ie = R.vision_encoder_forward(sd, img, arch.vit.heads, arch.vit.patch)["embeddings"]
+    tx = R.text_encoder_forward(sd, ids, mask, arch.gpt.heads)
+    ref = R.nt_xent(torch.nn.functional.normalize(ie, dim=-1), torch.nn.functional.normalize(tx["embeddings"], dim=-1), tau)
+    ref.backward()
+    print(f"full depth C2 stage 1: loss {loss:.5f} vs {float(ref):.5f}")
+    assert abs(loss - float(ref)) <= 5e-3, (loss, float(ref))
+    tt = "text_encoder.text_model."
+    worst = 1.0
+    for name in (tt + "wte.weight", tt + "wpe.weight", tt + "h.0.attn.c_attn.weight", tt + "h.0.mlp.c_fc.weight",
+                 tt + "h.0.ln_1.weight", tt + "h.12.attn.c_proj.weight", tt + "h.23.attn.c_attn.weight",
+                 tt + "h.23.mlp.c_proj.weight", tt + "h.23.mlp.c_fc.bias", tt + "ln_f.weight",
+                 "text_encoder.projection.0.weight", "text_encoder.projection.3.weight",
+                 "text_encoder.projection.4.weight"):
+        c = cos(model.store.g(name), sd[name].grad)
+        worst = min(worst, c)
+        assert c >= 0.99, f"{name}: cosine {c}"
+    print(f"full depth C2 stage 1: worst text-side gradient cosine {worst:.5f}")
+
+
+def test_heads_and_ntxent_backward_on_shipped_init_isolated_from_tower_noise(full_c2):
+    """The Stage-1 gradient of the VISION head on the shipped N(0, 0.02) initialisation, with nothing re-conditioned.
+
+    Against the oracle's own towers this gradient measured cosine 0.954-0.963 at depth 2 (round 2).  Its source is named
+    here by removing it: the oracle is given the HIP towers' pooled outputs (``vit.pooled``, ``text.pooled``), so both
+    sides push the SAME pooled vectors through head -> F.normalize -> NT-Xent and back.  What is left is the head + loss
+    arithmetic itself, which must meet the ordinary bound (>= 0.99).  The remainder therefore was the bf16 error of the
+    frozen ViT's pooled output: with random weights the class token is nearly the same for every image, the contrastive
+    gradient only sees the differences BETWEEN images (a few % of the pooled norm), and that is the size of the tower's
+    bf16 rounding - the same relative error that is invisible (cosine 0.999+) on the features themselves."""
+    from pgca_amd.steps import ContrastiveStep
+    model, arch = full_c2
+    gen = torch.Generator().manual_seed(33)
+    B, S, tau = 8, 128, 0.5
+    img = torch.randn(B, 3, 224, 224, generator=gen)
+    ids, mask = ragged(B, S, [128, 40, 77, 16, 100, 64, 33, 120], gen)
+    step = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                           model.text_encoder.engine, temperature=tau)
+    p = ContrastiveStep.prepare({"image": img, "caption_ids": ids, "caption_mask": mask}, model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss = float(step.loss_and_grads(p["image"], p["ids"], p["mask"], pack=p["pack"]))
+    vp = model.ws.bufs["vit.pooled"][:B * arch.vit.hidden].view(B, -1).cpu().clone()
+    tp = model.ws.bufs["text.pooled"][:B * arch.gpt.hidden].view(B, -1).cpu().clone()
+    heads = ("vision_encoder.projection", "text_encoder.projection")
+    sd = {k: v.detach().cpu().clone().requires_grad_(True)
+          for k, v in model.store.state_dict(aliases=False).items() if k.startswith(heads)}
+    # the engine feeds the heads bf16-rounded pooled vectors (GEMM operand); so does the oracle here
+    ie = R.projection_head(vp.bfloat16().float(), sd, heads[0])
+    te = R.projection_head(tp.bfloat16().float(), sd, heads[1])
+    ref = R.nt_xent(torch.nn.functional.normalize(ie, dim=-1), torch.nn.functional.normalize(te, dim=-1), tau)
+    ref.backward()
+    assert abs(loss - float(ref)) <= 2e-3, (loss, float(ref))
+    worst = 1.0
+    for name, t in sd.items():
+        c = cos(model.store.g(name), t.grad)
+        worst = min(worst, c)
+        assert c >= 0.99, f"{name}: cosine {c}"
+    # and against the oracle's OWN towers (unscaled weights): the number the isolation explains
+    sd_full = {k: v.detach().cpu().clone().requires_grad_(k.startswith(heads))
+               for k, v in model.store.state_dict(aliases=False).items()}
+    ie2 = R.vision_encoder_forward(sd_full, img, arch.vit.heads, arch.vit.patch)
+    tx2 = R.text_encoder_forward(sd_full, ids, mask, arch.gpt.heads)
+    R.nt_xent(torch.nn.functional.normalize(ie2["embeddings"], dim=-1),
+              torch.nn.functional.normalize(tx2["embeddings"], dim=-1), tau).backward()
+    c_tower = cos(model.store.g(heads[0] + ".0.weight"), sd_full[heads[0] + ".0.weight"].grad)
+    pooled_cos = cos(vp, ie2["pooled_output"].detach())
+    centred = cos(vp - vp.mean(0, keepdim=True), (ie2["pooled_output"] - ie2["pooled_output"].mean(0, keepdim=True)).detach())
+    print(f"shipped init: head+NT-Xent isolated worst cosine {worst:.5f}; vs oracle towers vision-head cosine {c_tower:.4f} "
+          f"(pooled cosine {pooled_cos:.6f}, image-to-image part of pooled cosine {centred:.4f})")
+    assert pooled_cos >= 0.999
+
+
+def test_c5_width_stage1_then_stage2_carry_over():
+    """BASELINE config C5's Stage-1 half at ViT-L/14 + GPT-2-XL width (depth 2), one optimiser step, then a Stage-2 step on
+    the weights Stage 1 left: each compared with the oracle on the model's then-current state_dict."""
+    from pgca_amd.arch import make_arch, with_layers
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    from pgca_amd.steps import ContrastiveStep, DPOStep, FusedOptimizer
+    arch = with_layers(make_arch("openai/clip-vit-large-patch14", "gpt2-xl", 512), 2, 2)
+    model = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=arch, seed=77, device="cuda:0")
+    gen = torch.Generator().manual_seed(34)
+    B, S, tau = 4, 256, 0.5
+    img = torch.randn(B, 3, 224, 224, generator=gen)
+    ids, mask = ragged(B, S, [256, 130, 77, 200], gen)
+    st1 = ContrastiveStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                          model.text_encoder.engine, temperature=tau)
+    segs = [model.store.segments[n] for n in ("vision_head", "text_head", "text_tower")]
+    opt = FusedOptimizer(segs, lr=5e-3, weight_decay=0.01, max_grad_norm=1.0, warmup_steps=0, total_steps=10)
+    p = ContrastiveStep.prepare({"image": img, "caption_ids": ids, "caption_mask": mask}, model.device)
+    opt.zero_grad()
+    loss1 = float(st1.loss_and_grads(p["image"], p["ids"], p["mask"], pack=p["pack"]))
+    sd = {k: v.detach().cpu().clone().requires_grad_(k.startswith(("text_encoder", "vision_encoder.projection")))
+          for k, v in model.store.state_dict(aliases=False).items()}
+    ie = R.vision_encoder_forward(sd, img, arch.vit.heads, arch.vit.patch)["embeddings"]
+    tx = R.text_encoder_forward(sd, ids, mask, arch.gpt.heads)
+    ref1 = R.nt_xent(torch.nn.functional.normalize(ie, dim=-1), torch.nn.functional.normalize(tx["embeddings"], dim=-1), tau)
+    ref1.backward()
+    assert abs(loss1 - float(ref1)) <= 5e-3, (loss1, float(ref1))
+    tt = "text_encoder.text_model."
+    for name in (tt + "wte.weight", tt + "h.0.attn.c_attn.weight", tt + "h.1.mlp.c_fc.weight", tt + "h.1.mlp.c_proj.weight",
+                 tt + "h.0.ln_2.weight", tt + "ln_f.weight", "text_encoder.projection.0.weight",
+                 "text_encoder.projection.4.weight"):
+        c = cos(model.store.g(name), sd[name].grad)
+        assert c >= 0.99, f"stage 1 {name}: cosine {c}"
+    before = model.store.w("vision_encoder.projection.0.weight").clone()
+    opt.step()
+    assert float((model.store.w("vision_encoder.projection.0.weight") - before).abs().max()) > 0.0
+    # ---- Stage 2 on the carried-over weights (the vision head Stage 1 just moved feeds the decoder)
+    st2 = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                  model.caption_decoder.engine, beta=0.1, reference_free=True)
+    ids2, mask2 = ragged(4, S, [256, 130, 77, 200], gen)
+    img2 = img[:2]
+    pb = DPOStep.prepare({"image": img2, "preferred_ids": ids2[:2], "rejected_ids": ids2[2:], "preferred_mask": mask2[:2],
+                          "rejected_mask": mask2[2:]}, model.device)
+    for s in model.store.trainable_segments():
+        s.grad.zero_()
+    loss2 = float(st2.loss_and_grads(pb["image"], pb["seq"]))
+    sd2 = {k: v.detach().cpu().clone().requires_grad_(k.startswith(("caption_decoder", "vision_encoder.projection")))
+           for k, v in model.store.state_dict(aliases=False).items()}
+    lw = R.model_forward(sd2, img2, ids2[:2], mask2[:2], "generation", arch.vit.heads, arch.vit.patch, arch.gpt.heads)["logits"]
+    ll = R.model_forward(sd2, img2, ids2[2:], mask2[2:], "generation", arch.vit.heads, arch.vit.patch, arch.gpt.heads)["logits"]
+    ref2 = R.preference_loss(lw, ll, ids2[:2], ids2[2:], mask2[:2], mask2[2:], 0.1)
+    ref2.backward()
+    assert abs(loss2 - float(ref2)) <= 5e-3, (loss2, float(ref2))
+    dec = "caption_decoder.lm_model.transformer."
+    for name in (dec + "wte.weight", dec + "h.0.attn.c_attn.weight", dec + "h.1.mlp.c_proj.weight", dec + "ln_f.weight",
+                 "caption_decoder.vision_projection.0.weight", "vision_encoder.projection.0.weight"):
+        c = cos(model.store.g(name), sd2[name].grad)
+        assert c >= 0.99, f"stage 2 after stage 1 {name}: cosine {c}"

@@ -60,3 +60,51 @@ def test_matches_torch_adamw_with_per_micro_batch_clipping():
     _, o2 = _run(None, False)                    # one clip per optimiser step: different first moments (AdamW's update is
     differs = any(not torch.allclose(o2["exp_avg"][k], o["exp_avg"][k], rtol=1e-4) for k in ("w", "b"))   # scale-free,
     assert differs                                # so compare the moments, not the weights
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Pinned against the reference trainer itself: tests/golden/trainer_epoch.npz holds a run of the reference's own
+# _train_epoch_stage2 / _train_epoch_stage1 (training/trainer.py:575-647, :464-539) under a real accelerate.Accelerator
+# (oracle/make_trainer_golden.py).  The restatement must reproduce it micro-batch by micro-batch.
+import json  # noqa: E402
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("stage", [2, 1])
+def test_loop_restatement_reproduces_the_reference_trainer(golden, stage):
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.params import ParamStore
+    g = golden("trainer_epoch")
+    meta = json.loads(str(g["meta"]))
+    arch = tiny_arch()
+    store = ParamStore(arch, "cpu", seed=int(meta["seed"]), frozen=())
+    sd = {k: v.clone() for k, v in store.state_dict(aliases=False).items()}
+    pre = f"s{stage}_"
+    n = int(g[pre + "n_batches"])
+    keys = ("image", "caption_ids", "caption_mask") if stage == 1 else \
+        ("image", "preferred_ids", "preferred_mask", "rejected_ids", "rejected_mask")
+    batches = [{k: torch.from_numpy(g[f"{pre}batch{i}_{k}"]) for k in keys} for i in range(n)]
+    trained = json.loads(str(g[pre + "trained_names"]))
+    trained = [t for t in trained if t in sd]                  # (aliases of the tower keys are the same tensors)
+    loss_fn = TR.stage1_loss(arch, meta["tau"]) if stage == 1 else TR.stage2_loss(arch, meta["beta"])
+    out = TR.run_epochs(sd, trained, batches, loss_fn, stage=stage, accum=meta["accum"], epochs=meta["epochs"],
+                        lr=meta["lr"], warmup=meta["warmup"], total_steps=(n // meta["accum"]) * meta["epochs"],
+                        max_norm=meta["max_norm"], clip_every_micro_step=True)
+    want = g[pre + "losses"]
+    got = np.array(out["losses"])
+    assert np.array_equal(np.isnan(got), np.isnan(want)), (got, want)          # the NaN micro-batches, in place
+    ok = ~np.isnan(want)
+    # every later loss depends on every earlier update: a wrong boundary / skip / clip / schedule rule shows up here
+    np.testing.assert_allclose(got[ok], want[ok], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(np.array(out["lr_in_force"]), g[pre + "lrs"], rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(np.array(out["epoch_means"]), g[pre + "epoch_means"], atol=2e-5)
+    assert out["global_step"] == int(g[pre + "global_step"])
+    assert out["opt_steps"] == int(g[pre + "opt_steps"])
+    for name in trained:
+        t = sd[name].detach().double().flatten()
+        s_want = g["s%d_final_sum::%s" % (stage, name)]
+        assert abs(float(t.sum()) - s_want[0]) <= 1e-4 * max(1.0, s_want[1]), name
+        np.testing.assert_allclose(t[::max(1, t.numel() // 64)][:64].numpy(), g["s%d_final_sample::%s" % (stage, name)],
+                                   atol=2e-5, err_msg=name)
