@@ -62,7 +62,8 @@ enum {
   PGCA_EPI_DTANH = 7,      /* v *= 1 - aux_in[m,n]^2     (aux_in = saved activation) */
   PGCA_EPI_ROWSTATS = 8,   /* no C written: per-row partial (max, sum exp) over this block's columns
                               + target-logit pick; fused LM head / NT-Xent (model.py:1069-1079,988-998) */
-  PGCA_EPI_DLOGITS = 9,    /* v = row_scale[m] * (exp(v - row_lse[m]) - (n == target[m])); 0 for n >= N */
+  PGCA_EPI_DLOGITS = 9,    /* v = row_scale[m] * (exp(v - row_lse[m]) - (n == target[m])); 0 for n >= N;
+                              aux_out (opt., bf16 [M, ld_aux]) <- bf16(v - bf16(v)): low half of a hi/lo split */
   PGCA_EPI_DQUICK_GELU = 10 /* v *= quick_gelu'(aux_in[m,n]) (aux_in = saved pre-activation; trainable CLIP tower) */
 };
 
@@ -180,7 +181,8 @@ int pgca_colsum(const void* x_bf16, const float* x_f32, int32_t M, int32_t N, in
  * accumulators of every 128-query block in registers: S <= PGCA_ATTN_MAX_S.  B <= 65535.
  * Replaces SDPA at modeling_gpt2.py:54-72,203-215 and modeling_clip.py:259-277.
  * Packed (variable-length) rows: with cu_seqlens (int32 [B+1], cu[0] = 0) sequence b occupies rows cu[b] .. cu[b+1]-1 of
- * qkv / out / dout / dqkv and has cu[b+1]-cu[b] <= S tokens; S stays the PADDED length: key_mask, lse and the dropout index
+ * qkv / out / dout / dqkv and has min(cu[b+1]-cu[b], S) tokens (a KV-cache decode step passes the cache stride in cu and
+ * the filled length as S, with no mask, lse or dropout); in training S stays the PADDED length: key_mask, lse and the dropout index
  * keep their [B, S] geometry, so the result of every real token equals the padded launch's.  Padding positions of the
  * reference batch (model.py:1069-1083 zeroes their loss terms, :449-456 their pooling weight) are then never computed. */
 #define PGCA_ATTN_MAX_S 512

@@ -340,6 +340,45 @@ def gen_optimizer():
     np.savez_compressed(os.path.join(OUT, "optimizer.npz"), **out)
 
 
+def gen_generation(comp, refmodel):
+    """The reference's own ``CaptionDecoder.generate`` (model.py:621-678 -> HF ``generate(inputs_embeds=...)`` with its
+    K/V cache) on the tiny geometry with OUR weights: greedy and deterministic beam search (``do_sample=False``; the
+    sampling modes draw from torch's RNG stream and cannot be replayed), with and without an EOS that actually occurs."""
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.params import ParamStore
+    arch = tiny_arch()
+    store = ParamStore(arch, "cpu", seed=17, frozen=())
+    sd = {k: v.clone() for k, v in store.state_dict().items()}
+    m = build_reference_model(refmodel, arch, sd)
+    g = torch.Generator().manual_seed(2)
+    img = torch.randn(5, 3, arch.vit.image, arch.vit.image, generator=g)
+    pad, eos = arch.gpt.base_vocab, arch.gpt.base_vocab + 2
+    out = {"meta": meta(), "seed": np.int64(17), "images": np_(img), "pad": np.int64(pad), "eos": np.int64(eos)}
+    with torch.no_grad():
+        emb = m.vision_encoder(img)["embeddings"]
+        out["embeddings"] = np_(emb)
+        cd = m.caption_decoder
+        cases = {"greedy": dict(max_length=12, num_beams=1, do_sample=False, repetition_penalty=1.1),
+                 "greedy_norep": dict(max_length=9, num_beams=1, do_sample=False, repetition_penalty=1.0),
+                 "beam4": dict(max_length=8, num_beams=4, do_sample=False, repetition_penalty=1.0),
+                 "beam3_rep": dict(max_length=10, num_beams=3, do_sample=False, repetition_penalty=1.2)}
+        for name, kw in cases.items():
+            ids = cd.generate(emb, pad_token_id=pad, eos_token_id=eos, **kw)
+            out[name + "_ids"] = np_(ids)
+            out[name + "_kw"] = json.dumps(kw)
+        # an EOS that occurs: the token greedy produces at step 2 for image 0 ends that caption
+        first = int(out["greedy_norep_ids"][0, 2])
+        out["eos_case_eos"] = np.int64(first)
+        out["greedy_eos_ids"] = np_(cd.generate(emb, max_length=9, num_beams=1, do_sample=False, repetition_penalty=1.0,
+                                                pad_token_id=pad, eos_token_id=first))
+        out["beam4_eos_ids"] = np_(cd.generate(emb, max_length=8, num_beams=4, do_sample=False, repetition_penalty=1.0,
+                                               pad_token_id=pad, eos_token_id=first))
+    np.savez_compressed(os.path.join(OUT, "generation.npz"), **out)
+    for k in out:
+        if k.endswith("_ids"):
+            print(k, out[k].shape, out[k][0].tolist())
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -350,6 +389,7 @@ def main():
     gen_logprob_dpo(comp, refmodel)
     gen_tiny_e2e(comp, refmodel)
     gen_tiny_vit_grads(comp, refmodel)
+    gen_generation(comp, refmodel)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -309,19 +309,37 @@ def generate_step_logits(sd: SD, vision_embeddings: torch.Tensor, ids: torch.Ten
     return h[:, -1] @ sd[p + ".lm_model.transformer.wte.weight"].t()
 
 
+def process_scores(scores: torch.Tensor, ids: torch.Tensor, repetition_penalty: float = 1.0, warp: bool = False,
+                   temperature: float = 1.0, top_p: float = 1.0) -> torch.Tensor:
+    """HF's processors in HF's order (transformers generation/logits_process.py: RepetitionPenaltyLogitsProcessor,
+    TemperatureLogitsWarper, TopPLogitsWarper with ``min_tokens_to_keep=1``), pinned against the installed classes by
+    tests/test_oracle_golden.py."""
+    if repetition_penalty != 1.0 and ids.shape[1]:
+        seen = torch.gather(scores, 1, ids)
+        scores = scores.scatter(1, ids, torch.where(seen < 0, seen * repetition_penalty, seen / repetition_penalty))
+    if warp:
+        if temperature != 1.0:
+            scores = scores / temperature
+        if top_p < 1.0:
+            srt, idx = torch.sort(scores, descending=False)
+            rm = torch.softmax(srt, dim=-1).cumsum(dim=-1) <= (1 - top_p)
+            rm[..., -1:] = False
+            scores = scores.masked_fill(rm.scatter(1, idx, rm), float("-inf"))
+    return scores
+
+
 def generate_greedy(sd: SD, vision_embeddings: torch.Tensor, max_length: int, heads: int, pad: int, eos: int,
                     repetition_penalty: float = 1.0):
-    """``num_beams=1, do_sample=False`` of HF generate with the repetition-penalty processor; returns
-    (ids [B, <= max_length], per-step top-2 logit margins) - the margins tell a bf16 comparison where a tie could flip."""
+    """``num_beams=1, do_sample=False`` of the reference's ``CaptionDecoder.generate`` (model.py:657-675 -> HF ``generate``
+    from ``inputs_embeds``): the prefix embedding counts as one of the ``max_length`` positions, so at most
+    ``max_length - 1`` tokens are produced (generation/utils.py ``_prepare_generated_length``).  Returns
+    (ids [B, <= max_length - 1], per-step top-2 logit margins) - the margins tell a bf16 comparison where a tie could flip."""
     b = vision_embeddings.shape[0]
     ids = torch.zeros(b, 0, dtype=torch.long)
     done = torch.zeros(b, dtype=torch.bool)
     margins = []
-    for _ in range(max_length):
-        logits = generate_step_logits(sd, vision_embeddings, ids, heads).clone()
-        if repetition_penalty != 1.0 and ids.shape[1]:
-            seen = torch.gather(logits, 1, ids)
-            logits.scatter_(1, ids, torch.where(seen < 0, seen * repetition_penalty, seen / repetition_penalty))
+    for _ in range(max_length - 1):
+        logits = process_scores(generate_step_logits(sd, vision_embeddings, ids, heads).clone(), ids, repetition_penalty)
         top2 = logits.topk(2, dim=-1).values
         margins.append(top2[:, 0] - top2[:, 1])
         nxt = torch.where(done, torch.full((b,), pad), logits.argmax(dim=-1))
@@ -330,6 +348,60 @@ def generate_greedy(sd: SD, vision_embeddings: torch.Tensor, max_length: int, he
         if bool(done.all()):
             break
     return ids, torch.stack(margins, dim=1)
+
+
+def generate_beam_search(sd: SD, vision_embeddings: torch.Tensor, max_length: int, num_beams: int, heads: int, pad: int,
+                         eos: int, repetition_penalty: float = 1.0):
+    """``num_beams > 1, do_sample=False``: HF ``_beam_search`` (transformers 5.x generation/utils.py) with its defaults
+    ``length_penalty=1.0``, ``early_stopping=False``: log-softmax first, processors on the log-probabilities,
+    ``2 * num_beams`` candidates per step, a finished-hypothesis pool fed only from the first ``num_beams`` ranks, the
+    best-possible-running-score stop heuristic.  Returns (ids [B, len], min top-(2 nb) gap per step) - the gap says where
+    a bf16 comparison may legitimately reorder candidates."""
+    B, nb = vision_embeddings.shape[0], num_beams
+    L, K2 = max_length - 1, 2 * num_beams
+    emb = vision_embeddings.repeat_interleave(nb, dim=0)
+    run = torch.full((B, nb, L), pad, dtype=torch.long)
+    seqs = run.clone()
+    run_sc = torch.zeros(B, nb)
+    run_sc[:, 1:] = -1e9
+    fin_sc = torch.full((B, nb), -1e9)
+    fin = torch.zeros(B, nb, dtype=torch.bool)
+    unsat = torch.ones(B, 1, dtype=torch.bool)
+    mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(nb, dtype=torch.bool)])
+    glen = torch.zeros(B, nb, dtype=torch.long)
+    ar = torch.arange(B)[:, None]
+    gaps = []
+    cur = 0
+    while True:
+        flat = run.view(B * nb, L)[:, :cur]
+        lp = torch.log_softmax(generate_step_logits(sd, emb, flat, heads).float(), dim=-1)
+        lp = process_scores(lp, flat, repetition_penalty)
+        V = lp.shape[1]
+        acc = (lp.view(B, nb, V) + run_sc[:, :, None]).view(B, nb * V)
+        top, idx = torch.topk(acc, k=K2 + 1)
+        gaps.append((top[:, :-1] - top[:, 1:]).min(dim=1).values)
+        top, idx = top[:, :K2], idx[:, :K2]
+        src, tok = idx // V, idx % V
+        cand = run[ar, src]
+        cand[:, :, cur] = tok
+        hits = (tok == eos) | (cur + 1 >= L)
+        rlp = top + hits.float() * -1e9
+        ni = torch.topk(rlp, k=nb)[1]
+        run, run_sc = cand[ar, ni], torch.gather(rlp, 1, ni)
+        just = hits & mask[None, :]
+        flp = top / float(cur + 1) + (~unsat).float() * -1e9 + (~just).float() * -1e9
+        m_seq, m_sc = torch.cat([seqs, cand], 1), torch.cat([fin_sc, flp], 1)
+        m_fin = torch.cat([fin, just], 1)
+        m_len = torch.cat([glen, torch.full((B, K2), cur + 1, dtype=torch.long)], 1)
+        keep = torch.topk(m_sc, k=nb)[1]
+        seqs, fin_sc, fin, glen = m_seq[ar, keep], torch.gather(m_sc, 1, keep), torch.gather(m_fin, 1, keep), \
+            torch.gather(m_len, 1, keep)
+        cur += 1
+        worst = torch.where(fin, fin_sc.min(dim=1, keepdim=True)[0], torch.full_like(fin_sc, -1e9))
+        unsat = unsat & (run_sc[:, :1] / float(cur) > worst).any(dim=-1, keepdim=True)
+        if cur >= L or not bool(unsat.any() & ~hits.all()):
+            break
+    return seqs[:, 0, :max(1, int(glen[:, 0].max()))], torch.stack(gaps, dim=1)
 
 
 def model_forward(sd: SD, images: torch.Tensor, caption_ids: torch.Tensor, caption_mask: torch.Tensor,

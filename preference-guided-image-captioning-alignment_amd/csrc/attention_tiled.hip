@@ -96,7 +96,7 @@ __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __
   // sequence's tokens are rows cu[b] .. cu[b+1]-1 and S is their count; otherwise rows b*Sp .. and S == Sp.
   const int h = blockIdx.x, b = blockIdx.y, qb = blockIdx.z;
   const int row0 = cu ? cu[b] : b * Sp;
-  if (cu) S = cu[b + 1] - row0;
+  if (cu) S = min(S, cu[b + 1] - row0);   // (a KV-cache launch gives cu the cache stride and S the filled length)
   if (qb * TB >= S) return;  // block-uniform: a short (or empty) sequence has no such query block
   const int H = heads * DH, ld = 3 * H;
   const int t = threadIdx.x, lane = t & 63;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
 
   const int h = blockIdx.x, b = blockIdx.y;
   const int row0 = cu ? cu[b] : b * Sp;  // packed rows: see the forward
-  if (cu) S = cu[b + 1] - row0;
+  if (cu) S = min(S, cu[b + 1] - row0);
   if (S <= 0) return;
   const int H = heads * DH, ld = 3 * H;
   const int t = threadIdx.x, lane = t & 63;

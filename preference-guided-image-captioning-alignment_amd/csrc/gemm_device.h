@@ -304,6 +304,11 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
       for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
     }
   }
+  if (EPI == PGCA_EPI_DLOGITS && a.aux_out) {  // low half of the hi/lo bf16 split of the result (NT-Xent: f32-grade G)
+    bf16_t* p = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j] - bf2f(f2bf(v[j])));
+  }
 }
 
 // ---- wave-private staging slab -------------------------------------------------------------------------
@@ -466,6 +471,12 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
 #pragma unroll
         for (int j = 0; j < 8; ++j) tq[j] = f2bf(v[j]);
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.out_bf16) + (size_t)row * a.ld_out_bf16 + col) = tq;
+      }
+      if (EPI == PGCA_EPI_DLOGITS && a.aux_out) {
+        bf16x8 tq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tq[j] = f2bf(v[j] - bf2f(f2bf(v[j])));
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col) = tq;
       }
     }
   }

@@ -372,6 +372,57 @@ class GptTrunk:
             self.saved = sv
         return h
 
+    # -- incremental decoding (generation) ---------------------------------------------------------
+    def decode_cache(self, R: int, smax: int) -> dict:
+        """Per-layer K/V cache of an incremental decode over ``R`` sequences of at most ``smax`` positions: one resident
+        ``[R * smax, 3H]`` bf16 buffer per layer in the SAME q|k|v row layout the attention kernel reads (row r*smax + t
+        holds position t of sequence r), plus the shared attention-output rows and the offsets ``cu[r] = r * smax``."""
+        a, H = self.arch, self.arch.hidden
+        if smax > a.n_pos:
+            raise ValueError(f"{smax} positions exceed GPT-2's {a.n_pos} learned positions")
+        kv = [self._buf(f"gen.kv{li}", (R * smax, 3 * H), BF16) for li in range(len(self.layers))]
+        att = self._buf("gen.att", (R * smax, H), BF16)
+        cu = self.ws.bufs.get(self.tag + ".gen.cu")
+        if cu is None or cu.numel() != R + 1 or int(getattr(self, "_gen_smax", -1)) != smax:
+            cu = (torch.arange(R + 1, dtype=I32, device=self.ws.device) * smax).contiguous()
+            self.ws.bufs[self.tag + ".gen.cu"] = cu
+            self._gen_smax = smax
+        return dict(kv=kv, att=att, cu=cu, R=R, smax=smax)
+
+    def decode_step(self, x: torch.Tensor, st: dict, t: int) -> torch.Tensor:
+        """One position of an incremental forward: ``x`` [R, H] f32 is the input embedding (+ position) of position
+        ``t`` of every sequence; keys / values of positions < t come from the cache ``st`` (HF ``use_cache``,
+        modeling_gpt2.py:144-226 with ``layer_past``).  Updates ``x`` in place to the residual stream after the last
+        block and returns it.  The query rows of the cached positions ride along in the attention launch (their outputs
+        are rewritten with the values they already had): at caption lengths (<= 128: one key tile) that costs nothing
+        next to the weight reads of the R-row GEMMs."""
+        a, H, I = self.arch, self.arch.hidden, self.arch.inner
+        R, smax = st["R"], st["smax"]
+        if not 0 <= t < smax:
+            raise ValueError(f"position {t} outside the cache ({smax})")
+        y = self._buf("gen.y", (R, H), BF16)
+        act = self._buf("gen.act", (R, I), BF16)
+        att = st["att"]
+        att_t = att.view(-1)[t * H:]
+        for li, P in enumerate(self.layers):
+            kv = st["kv"][li]
+            hip.layernorm_fwd(x, R, H, P["ln1w"].w, P["ln1b"].w, a.eps, y_bf16=y)
+            hip.gemm(y, P["wqkv"].b, R, 3 * H, H, hip.NN, bias=P["bqkv"].w, out_bf16=kv.view(-1)[t * 3 * H:],
+                     ld_out_bf16=smax * 3 * H)
+            hip.attention_fwd(kv, None, R, t + 1, a.heads, True, att, None, cu=st["cu"])
+            hip.gemm(att_t, P["wo"].b, R, H, H, hip.NN, lda=smax * H, bias=P["bo"].w, residual=x, out_f32=x)
+            hip.layernorm_fwd(x, R, H, P["ln2w"].w, P["ln2b"].w, a.eps, y_bf16=y)
+            hip.gemm(y, P["wfc"].b, R, I, H, hip.NN, epilogue=hip.EPI_GELU_NEW, bias=P["bfc"].w, out_bf16=act)
+            hip.gemm(act, P["wpr"].b, R, H, I, hip.NN, bias=P["bpr"].w, residual=x, out_f32=x)
+        return x
+
+    def decode_reorder(self, st: dict, src: torch.Tensor) -> None:
+        """Beam search: sequence r continues from cached sequence ``src[r]`` (HF ``_reorder_cache``)."""
+        R, smax = st["R"], st["smax"]
+        for li, kv in enumerate(st["kv"]):
+            v = kv.view(R, smax, -1)
+            v.copy_(v.index_select(0, src))
+
     def top_drop(self):
         """Dropout triple the producer of ``g_bf`` (the ln_f backward) must apply: last layer's mlp dropout."""
         drop = self.saved.get("drop") if self.saved else None
@@ -878,8 +929,9 @@ class CaptionDecoderEngine:
         """Logits of the next token given the prefix embedding ``pv`` [B, H] and the tokens generated so far ``ids``
         [B, t] (t >= 0): GPT-2 on ``[pv, wte(ids)] + wpe`` (``inputs_embeds`` path of HF generate: no cross-attention,
         no attention_norm - the reference feeds the projected vision vector straight to ``lm_model.generate``), causal
-        attention, ``ln_f`` + tied LM head on the last position only.  The prefix is recomputed every step (captions are
-        <= 50 tokens; no KV cache)."""
+        attention, ``ln_f`` + tied LM head on the last position only.  This is the CACHE-FREE form - the whole prefix is
+        recomputed - kept as the cross-check of the K/V-cache path (``decode_begin`` / ``decode_advance``) that
+        ``generate`` runs."""
         a = self.arch.gpt
         B, t = ids.shape
         H, S = a.hidden, t + 1
@@ -896,6 +948,40 @@ class CaptionDecoderEngine:
         ldv = (self.V + 3) // 4 * 4
         out = torch.empty(B, ldv, dtype=F32, device=self.ws.device)
         hip.gemm(hf, self.wte.b, B, self.V, H, hip.NT, out_f32=out, ld_out_f32=ldv)
+        return out[:, :self.V]
+
+    # -- incremental decoding with a K/V cache (what HF generate does with use_cache=True, reference model.py:657-670) ----
+    def decode_begin(self, pv: torch.Tensor, max_positions: int) -> torch.Tensor:
+        """Start an incremental decode from the prefix embeddings ``pv`` [R, H] (position 0); returns the logits of the
+        first token [R, V].  ``max_positions`` = 1 + the most tokens that will be fed back."""
+        R = pv.shape[0]
+        self._dec = self.trunk.decode_cache(R, int(max_positions))
+        self._dec["t"] = 0
+        x = self._buf("gen.x", (R, self.arch.gpt.hidden), F32)
+        torch.add(pv, self.wpe.w[0], out=x)
+        return self._decode_logits(x)
+
+    def decode_advance(self, tokens: torch.Tensor) -> torch.Tensor:
+        """Feed the tokens chosen for the current position ([R] int64); returns the next token's logits [R, V]."""
+        st = self._dec
+        st["t"] += 1
+        x = self._buf("gen.x", (st["R"], self.arch.gpt.hidden), F32)
+        torch.index_select(self.wte.w, 0, tokens, out=x)
+        x.add_(self.wpe.w[st["t"]])
+        return self._decode_logits(x)
+
+    def decode_reorder(self, src: torch.Tensor) -> None:
+        self.trunk.decode_reorder(self._dec, src)
+
+    def _decode_logits(self, x: torch.Tensor) -> torch.Tensor:
+        a, st = self.arch.gpt, self._dec
+        R, H = st["R"], a.hidden
+        self.trunk.decode_step(x, st, st["t"])
+        hf = self._buf("gen.hf", (R, H), BF16)
+        hip.layernorm_fwd(x, R, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_bf16=hf)
+        ldv = (self.V + 3) // 4 * 4
+        out = self._buf("gen.logits", (R, ldv), F32)
+        hip.gemm(hf, self.wte.b, R, self.V, H, hip.NT, out_f32=out, ld_out_f32=ldv)
         return out[:, :self.V]
 
     # -- backward -------------------------------------------------------------------------------
@@ -1150,28 +1236,36 @@ class NTXentEngine:
             self.ws.bufs[self.tag + ".targetsN"] = tgN
             self._tgN_key = (off, B)
         # G1[i in loc, j in all] = c (p^r_ij - d_ij);  G2[j in loc, i in all] = c (p^c_ij - d_ij)
-        g1 = self._buf("g1", (B, Np), BF16)
-        g2 = self._buf("g2", (B, Np), BF16)
+        # Each G leaves the DLOGITS epilogue as a hi + lo bf16 pair: at initialisation the embeddings of a batch are
+        # nearly parallel, P is nearly uniform and G.T is a difference of nearly equal vectors - a G rounded to bf16
+        # (2^-9) puts ~10 % noise on that difference (measured: head-gradient cosine 0.984), the pair keeps it at f32 level
+        def G(name, shape):
+            return self._buf(name, shape, BF16), self._buf(name + "_lo", shape, BF16)
+        g1, g1l = G("g1", (B, Np))
+        g2, g2l = G("g2", (B, Np))
         hip.gemm(bf["i"], bf["ta"], B, N, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
-                 row_lse=s["lse_r"], row_scale=cB, out_bf16=g1, ld_out_bf16=Np, out_cols=Np)
+                 row_lse=s["lse_r"], row_scale=cB, out_bf16=g1, ld_out_bf16=Np, out_cols=Np, aux_out=g1l, ld_aux=Np)
         hip.gemm(bf["t"], bf["ia"], B, N, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=s["tg"],
-                 row_lse=s["lse_c"], row_scale=cB, out_bf16=g2, ld_out_bf16=Np, out_cols=Np)
+                 row_lse=s["lse_c"], row_scale=cB, out_bf16=g2, ld_out_bf16=Np, out_cols=Np, aux_out=g2l, ld_aux=Np)
         # G1'[i in all, j in loc] = c (p^r_ij - d_ij);  G2'[j in all, i in loc] = c (p^c_ij - d_ij)
         # (operand roles swapped: [hi|lo|hi] . [hi|hi|lo] is the same three-term sum)
-        g1t = self._buf("g1t", (N, Bp), BF16)
-        g2t = self._buf("g2t", (N, Bp), BF16)
+        g1t, g1tl = G("g1t", (N, Bp))
+        g2t, g2tl = G("g2t", (N, Bp))
         hip.gemm(bf["ia"], bf["t"], N, B, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
-                 row_lse=lse_r_all, row_scale=cN, out_bf16=g1t, ld_out_bf16=Bp, out_cols=Bp)
+                 row_lse=lse_r_all, row_scale=cN, out_bf16=g1t, ld_out_bf16=Bp, out_cols=Bp, aux_out=g1tl, ld_aux=Bp)
         hip.gemm(bf["ta"], bf["i"], N, B, K3, hip.NT, epilogue=hip.EPI_DLOGITS, alpha=inv_tau, targets=tgN,
-                 row_lse=lse_c_all, row_scale=cN, out_bf16=g2t, ld_out_bf16=Bp, out_cols=Bp)
+                 row_lse=lse_c_all, row_scale=cN, out_bf16=g2t, ld_out_bf16=Bp, out_cols=Bp, aux_out=g2tl, ld_aux=Bp)
         dI = self._buf("dI", (B, P), F32)
         dT = self._buf("dT", (B, P), F32)
         # dI_loc = (1/tau) (G1 T_all + G2'^t T_all);  dT_loc = (1/tau) (G2 I_all + G1'^t I_all); the gathered
-        # tables enter as hi + lo (columns [0,P) and [P,2P) of the [hi|lo|hi] image, row stride 3P)
-        for part, acc in ((0, False), (1, True)):
+        # tables enter as hi + lo (columns [0,P) and [P,2P) of the [hi|lo|hi] image, row stride 3P), the G's likewise
+        first = True
+        for part in (0, 1):
             ta, ia = bf["ta"][:, part * P:], bf["ia"][:, part * P:]
-            hip.gemm(g1, ta, B, P, Np, hip.NN, lda=Np, ldb=K3, alpha=inv_tau, out_f32=dI, accumulate=acc)
-            hip.gemm(g2t, ta, B, P, N, hip.TN, lda=Bp, ldb=K3, alpha=inv_tau, out_f32=dI, accumulate=True)
-            hip.gemm(g2, ia, B, P, Np, hip.NN, lda=Np, ldb=K3, alpha=inv_tau, out_f32=dT, accumulate=acc)
-            hip.gemm(g1t, ia, B, P, N, hip.TN, lda=Bp, ldb=K3, alpha=inv_tau, out_f32=dT, accumulate=True)
+            for a1, a2t, b2, b1t in ((g1, g2t, g2, g1t), (g1l, g2tl, g2l, g1tl)):
+                hip.gemm(a1, ta, B, P, Np, hip.NN, lda=Np, ldb=K3, alpha=inv_tau, out_f32=dI, accumulate=not first)
+                hip.gemm(a2t, ta, B, P, N, hip.TN, lda=Bp, ldb=K3, alpha=inv_tau, out_f32=dI, accumulate=True)
+                hip.gemm(b2, ia, B, P, Np, hip.NN, lda=Np, ldb=K3, alpha=inv_tau, out_f32=dT, accumulate=not first)
+                hip.gemm(b1t, ia, B, P, N, hip.TN, lda=Bp, ldb=K3, alpha=inv_tau, out_f32=dT, accumulate=True)
+                first = False
         return dI, dT

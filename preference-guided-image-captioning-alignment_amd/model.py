@@ -207,19 +207,49 @@ class CaptionDecoder:
     __call__ = forward
 
     # -- generation --------------------------------------------------------------------------------
+    EOS_CHECK = 8    # tokens between two "has every sequence finished" host read-backs
+
+    @staticmethod
+    def _process_scores(scores: torch.Tensor, ids: torch.Tensor, repetition_penalty: float, warp: bool,
+                        temperature: float, top_p: float) -> torch.Tensor:
+        """HF's logits processors in HF's order (generation/logits_process.py): RepetitionPenaltyLogitsProcessor, then -
+        when sampling - TemperatureLogitsWarper and TopPLogitsWarper (keeps the smallest set with mass >= top_p, at
+        least one token).  ``scores`` are raw logits for greedy / sampling and log-probabilities for beam search."""
+        if repetition_penalty != 1.0 and ids.shape[1]:
+            seen = torch.gather(scores, 1, ids)
+            seen = torch.where(seen < 0, seen * repetition_penalty, seen / repetition_penalty)
+            scores = scores.scatter(1, ids, seen)
+        if warp:
+            if temperature != 1.0:
+                scores = scores / float(temperature)
+            if top_p < 1.0:
+                srt, idx = torch.sort(scores, dim=-1, descending=False)
+                cum = torch.softmax(srt, dim=-1).cumsum(dim=-1)
+                rm = cum <= (1.0 - float(top_p))
+                rm[:, -1] = False
+                scores = scores.masked_fill(rm.scatter(1, idx, rm), float("-inf"))
+        return scores
+
     @torch.no_grad()
     def generate(self, vision_features: torch.Tensor, max_length: int = 50, num_beams: int = 4,
                  temperature: float = 1.0, do_sample: bool = True, top_p: float = 0.9,
                  repetition_penalty: float = 1.1, pad_token_id: Optional[int] = None,
                  eos_token_id: Optional[int] = None, generator: Optional[torch.Generator] = None,
-                 **kwargs) -> torch.Tensor:
+                 use_cache: bool = True, **kwargs) -> torch.Tensor:
         """Reference ``CaptionDecoder.generate`` (model.py:621-678): HF ``generate`` started from the single embedding
-        ``vision_projection(vision_features)``.  Same arguments; returns generated ids ``[B, <= max_length]`` (int64,
-        padded with ``pad_token_id`` after ``eos_token_id``).  Logit processing as HF's processors: repetition penalty,
-        temperature, nucleus (top-p) filter.  ``num_beams == 1``: greedy / sampling.  ``num_beams > 1``: deterministic
-        beam search on the processed log-probabilities (HF's beam-*sample* draws from its own RNG stream and cannot be
-        reproduced; ``do_sample`` is honoured for one beam only).  Token ids default to the decoder tokenizer's
-        (model.py:509-511: [PAD] = vocab, [EOS] = vocab + 2)."""
+        ``vision_projection(vision_features)``.  Same arguments; returns the generated ids ``[B, <= max_length - 1]``
+        (int64; HF counts the prefix embedding as one of the ``max_length`` positions, generation/utils.py
+        ``_prepare_generated_length``), padded with ``pad_token_id`` after ``eos_token_id``.
+
+        ``num_beams == 1``: greedy / nucleus sampling on the processed logits.  ``num_beams > 1``: HF's beam search
+        restated step for step (generation/utils.py ``_beam_search``: log-softmax, processors on the log-probabilities,
+        ``2 * num_beams`` candidates, finished-hypothesis pool with ``length_penalty`` 1.0 and the ``early_stopping=False``
+        heuristic; ``do_sample`` draws the candidates with ``torch.multinomial`` as HF's beam-sample does).  Both pinned
+        against the reference's own ``generate`` on ``tests/golden/generation.npz`` (the sampling modes only in
+        distribution: torch's RNG stream differs).  Token ids default to the decoder tokenizer's (model.py:509-511:
+        [PAD] = vocab, [EOS] = vocab + 2).  ``use_cache`` (HF's default): every step feeds ONE position through the trunk
+        against per-layer K/V buffers (``engine.GptTrunk.decode_step``); ``False`` recomputes the prefix each step (the
+        cross-check)."""
         if kwargs:
             raise TypeError(f"unsupported generation arguments: {sorted(kwargs)}")
         eng, dev = self.engine, self._o.device
@@ -228,54 +258,109 @@ class CaptionDecoder:
         eos = base + 2 if eos_token_id is None else int(eos_token_id)
         emb = vision_features.to(dev, F32).contiguous()
         B, nb = emb.shape[0], max(1, int(num_beams))
+        L = int(max_length) - 1            # tokens to generate: the prefix embedding occupies one position
+        if L < 1:
+            raise ValueError(f"max_length={max_length} leaves no room for a generated token (the prefix counts as one)")
         pv = eng.prefix_embedding(emb)
         if nb > 1:
-            pv = pv.repeat_interleave(nb, dim=0)
-        R = B * nb
-        ids = torch.zeros(R, 0, dtype=I64, device=dev)
-        done = torch.zeros(R, dtype=torch.bool, device=dev)
-        score = torch.zeros(B, nb, device=dev)
-        if nb > 1:
-            score[:, 1:] = float("-inf")                     # all beams start identical: keep one alive
-        for _ in range(int(max_length)):
-            logits = eng.next_token_logits(pv, ids).clone()
-            if repetition_penalty != 1.0 and ids.shape[1]:   # HF RepetitionPenaltyLogitsProcessor
-                seen = torch.gather(logits, 1, ids)
-                seen = torch.where(seen < 0, seen * repetition_penalty, seen / repetition_penalty)
-                logits.scatter_(1, ids, seen)
-            if nb == 1 and do_sample:
-                if temperature != 1.0:
-                    logits = logits / float(temperature)
-                if top_p < 1.0:                              # HF TopPLogitsWarper (keeps the smallest set with mass >= top_p)
-                    srt, idx = torch.sort(logits, dim=-1, descending=False)
-                    cum = torch.softmax(srt, dim=-1).cumsum(dim=-1)
-                    rm = cum <= (1.0 - float(top_p))
-                    rm[:, -1] = False
-                    logits = logits.masked_fill(rm.scatter(1, idx, rm), float("-inf"))
-                nxt = torch.multinomial(torch.softmax(logits, dim=-1), 1, generator=generator)[:, 0]
-            elif nb == 1:
-                nxt = logits.argmax(dim=-1)
+            return self._beam_search(pv, B, nb, L, pad, eos, float(temperature), bool(do_sample), float(top_p),
+                                     float(repetition_penalty), generator, use_cache)
+        # ---- greedy / sampling (HF _sample): preallocated ids, one EOS read-back every EOS_CHECK tokens
+        ids_buf = torch.full((B, L), pad, dtype=I64, device=dev)
+        done = torch.zeros(B, dtype=torch.bool, device=dev)
+        n = 0
+        logits = eng.decode_begin(pv, L) if use_cache else None
+        while True:
+            ids = ids_buf[:, :n]
+            if not use_cache:
+                logits = eng.next_token_logits(pv, ids)
+            scores = self._process_scores(logits.clone(), ids, repetition_penalty, do_sample, temperature, top_p)
+            if do_sample:
+                nxt = torch.multinomial(torch.softmax(scores, dim=-1), 1, generator=generator)[:, 0]
             else:
-                logp = torch.log_softmax(logits, dim=-1)
-                frozen = torch.full_like(logp, float("-inf"))
-                frozen[:, pad] = 0.0                         # a finished beam only continues with [PAD], score unchanged
-                logp = torch.where(done[:, None], frozen, logp)
-                V = logp.shape[1]
-                cand = (score.view(R, 1) + logp).view(B, nb * V)
-                score, flat = cand.topk(nb, dim=-1)
-                src = flat // V + torch.arange(B, device=dev)[:, None] * nb
-                ids, done = ids[src.view(-1)], done[src.view(-1)]
-                nxt = (flat % V).view(-1)
+                nxt = scores.argmax(dim=-1)
             nxt = torch.where(done, torch.full_like(nxt, pad), nxt)
-            ids = torch.cat([ids, nxt[:, None]], dim=1)
+            ids_buf[:, n] = nxt
+            n += 1
             done = done | (nxt == eos)
-            if bool(done.all()):
+            if n == L or ((n % self.EOS_CHECK == 0) and bool(done.all())):   # the only host read-back of the loop
                 break
-        if nb > 1:                                           # best beam per image (length penalty 1.0 as HF's default)
-            length = (ids != pad).sum(dim=1).clamp(min=1).view(B, nb).float()
-            best = (score / length).argmax(dim=-1) + torch.arange(B, device=dev) * nb
-            ids = ids[best]
-        return ids
+            if use_cache:
+                logits = eng.decode_advance(nxt)
+        # columns generated after every sequence had finished are all [PAD]: trimming them equals stopping at once
+        alive = (ids_buf[:, :n] != pad).any(dim=0)
+        last_tok = int(alive.nonzero().max()) + 1 if bool(alive.any()) else 1
+        return ids_buf[:, :max(1, min(n, last_tok))]
+
+    def _beam_search(self, pv, B, nb, L, pad, eos, temperature, do_sample, top_p, repetition_penalty, generator,
+                     use_cache) -> torch.Tensor:
+        """HF ``GenerationMixin._beam_search`` (transformers 5.x, generation/utils.py) for ``length_penalty`` 1.0,
+        ``early_stopping`` False, one returned sequence: state tensors and update rules carry HF's names."""
+        eng, dev = self.engine, self._o.device
+        R, K2 = B * nb, 2 * nb                                   # beams_to_keep = 2 * num_beams (one EOS id)
+        pvr = pv.repeat_interleave(nb, dim=0)
+        running_sequences = torch.full((B, nb, L), pad, dtype=I64, device=dev)
+        sequences = running_sequences.clone()
+        running_beam_scores = torch.zeros(B, nb, device=dev)
+        running_beam_scores[:, 1:] = -1e9
+        beam_scores = torch.full((B, nb), -1e9, device=dev)
+        is_sent_finished = torch.zeros(B, nb, dtype=torch.bool, device=dev)
+        unsat = torch.ones(B, 1, dtype=torch.bool, device=dev)   # is_early_stop_heuristic_unsatisfied
+        top_num_beam_mask = torch.cat([torch.ones(nb, dtype=torch.bool), torch.zeros(nb, dtype=torch.bool)]).to(dev)
+        gen_len = torch.zeros(B, nb, dtype=I64, device=dev)      # tokens of each finished hypothesis (HF: beam_indices)
+        ar = torch.arange(B, device=dev)[:, None]
+        cur = 0
+        logits = eng.decode_begin(pvr, L) if use_cache else None
+        while True:
+            flat = running_sequences.view(R, L)[:, :cur]
+            if not use_cache:
+                logits = eng.next_token_logits(pvr, flat)
+            log_probs = torch.log_softmax(logits.float(), dim=-1)
+            log_probs = self._process_scores(log_probs, flat, repetition_penalty, do_sample, temperature, top_p)
+            V = log_probs.shape[1]
+            acc = (log_probs.view(B, nb, V) + running_beam_scores[:, :, None]).view(B, nb * V)
+            if do_sample:                                        # beam-sample: candidates drawn, then ranked by score
+                idx = torch.multinomial(torch.softmax(acc, dim=-1), num_samples=K2, generator=generator)
+                topk_log_probs = torch.gather(acc, 1, idx)
+            else:
+                topk_log_probs, idx = torch.topk(acc, k=K2)
+            src_beam = idx // V
+            topk_running = running_sequences[ar, src_beam]      # [B, 2nb, L]
+            topk_ids = idx % V
+            topk_running[:, :, cur] = topk_ids
+            hits = (topk_ids == eos) | (cur + 1 >= L)            # EosTokenCriteria | MaxLengthCriteria
+            # e. the num_beams best unfinished candidates keep running
+            run_lp = topk_log_probs + hits.float() * -1.0e9
+            nxt_idx = torch.topk(run_lp, k=nb)[1]
+            running_sequences = topk_running[ar, nxt_idx]
+            running_beam_scores = torch.gather(run_lp, 1, nxt_idx)
+            beam_src = torch.gather(src_beam, 1, nxt_idx)        # the beam each running sequence continues
+            # f. finished pool: only candidates ranked inside the first num_beams may finish
+            just = hits & top_num_beam_mask[None, :]
+            fin_lp = topk_log_probs / float(cur + 1)             # length_penalty 1.0
+            fin_lp = fin_lp + (~unsat).float() * -1.0e9 + (~just).float() * -1.0e9
+            m_seq = torch.cat([sequences, topk_running], dim=1)
+            m_sc = torch.cat([beam_scores, fin_lp], dim=1)
+            m_fin = torch.cat([is_sent_finished, just], dim=1)
+            m_len = torch.cat([gen_len, torch.full((B, K2), cur + 1, dtype=I64, device=dev)], dim=1)
+            keep = torch.topk(m_sc, k=nb)[1]
+            sequences, beam_scores = m_seq[ar, keep], torch.gather(m_sc, 1, keep)
+            is_sent_finished, gen_len = torch.gather(m_fin, 1, keep), torch.gather(m_len, 1, keep)
+            cur += 1
+            # g. stop? (_check_early_stop_heuristic with early_stopping=False, _beam_search_has_unfinished_sequences)
+            best_run = running_beam_scores[:, :1] / float(cur)
+            worst_fin = torch.where(is_sent_finished, beam_scores.min(dim=1, keepdim=True)[0],
+                                    torch.full_like(beam_scores, -1.0e9))
+            unsat = unsat & (best_run > worst_fin).any(dim=-1, keepdim=True)
+            if cur >= L or not bool(unsat.any() & ~hits.all()):
+                break
+            tok = torch.gather(topk_ids, 1, nxt_idx).view(R)
+            if use_cache:
+                flat_src = (beam_src + ar * nb).view(R)
+                eng.decode_reorder(flat_src)
+                logits = eng.decode_advance(tok)
+        out_len = max(1, int(gen_len[:, 0].max()))
+        return sequences[:, 0, :out_len].contiguous()
 
 
 class PreferenceGuidedCaptioningModel:

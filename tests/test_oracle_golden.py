@@ -231,3 +231,52 @@ def test_cross_attention_collapse(tiny):
     v = kv[:, 0] @ w[2 * h:].t() + b[2 * h:]
     col = v @ sd["caption_decoder.cross_attention.out_proj.weight"].t() + sd["caption_decoder.cross_attention.out_proj.bias"]
     np.testing.assert_allclose(full.detach().numpy(), col[:, None, :].expand(3, 7, h).detach().numpy(), atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ generation
+def test_generation_restatement_reproduces_the_reference_generate(golden):
+    """tests/golden/generation.npz holds ids produced by the REFERENCE's own CaptionDecoder.generate (model.py:621-678 ->
+    HF generate with its K/V cache) on the tiny model: greedy and deterministic beam search, with and without an EOS that
+    occurs.  The restatement (cache-free, HF's rules restated) must return the same ids."""
+    from pgca_amd.arch import tiny_arch
+    from pgca_amd.params import ParamStore
+    g = golden("generation")
+    arch = tiny_arch()
+    store = ParamStore(arch, "cpu", seed=int(g["seed"]), frozen=())
+    sd = {k: v.clone() for k, v in store.state_dict(aliases=False).items()}
+    emb = torch.from_numpy(g["embeddings"])
+    got_emb = R.vision_encoder_forward(sd, torch.from_numpy(g["images"]), arch.vit.heads, arch.vit.patch)["embeddings"]
+    np.testing.assert_allclose(got_emb.detach().numpy(), g["embeddings"], atol=1e-4)
+    pad, eos = int(g["pad"]), int(g["eos"])
+    import json
+    for name in ("greedy", "greedy_norep"):
+        kw = json.loads(str(g[name + "_kw"]))
+        ids, _ = R.generate_greedy(sd, emb, kw["max_length"], arch.gpt.heads, pad, eos, kw["repetition_penalty"])
+        assert np.array_equal(ids.numpy(), g[name + "_ids"]), name
+    for name in ("beam4", "beam3_rep"):
+        kw = json.loads(str(g[name + "_kw"]))
+        ids, _ = R.generate_beam_search(sd, emb, kw["max_length"], kw["num_beams"], arch.gpt.heads, pad, eos,
+                                        kw["repetition_penalty"])
+        assert np.array_equal(ids.numpy(), g[name + "_ids"]), name
+    e2 = int(g["eos_case_eos"])
+    ids, _ = R.generate_greedy(sd, emb, 9, arch.gpt.heads, pad, e2, 1.0)
+    assert np.array_equal(ids.numpy(), g["greedy_eos_ids"])
+    ids, _ = R.generate_beam_search(sd, emb, 8, 4, arch.gpt.heads, pad, e2, 1.0)
+    assert np.array_equal(ids.numpy(), g["beam4_eos_ids"])
+
+
+def test_score_processors_match_the_installed_transformers_classes():
+    """The repetition-penalty / temperature / top-p restatement against transformers' own processor classes."""
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                        TopPLogitsWarper)
+    gen = torch.Generator().manual_seed(8)
+    scores = torch.randn(6, 97, generator=gen) * 3
+    ids = torch.randint(0, 97, (6, 5), generator=gen)
+    want = RepetitionPenaltyLogitsProcessor(1.3)(ids, scores.clone())
+    want = TopPLogitsWarper(0.8)(ids, TemperatureLogitsWarper(0.7)(ids, want))
+    got = R.process_scores(scores.clone(), ids, 1.3, True, 0.7, 0.8)
+    assert torch.equal(torch.isinf(got), torch.isinf(want))
+    fin = ~torch.isinf(want)
+    assert torch.allclose(got[fin], want[fin], atol=1e-6)
+    lp = torch.log_softmax(scores, dim=-1)              # beam search feeds log-probabilities through the same classes
+    assert torch.allclose(R.process_scores(lp.clone(), ids, 1.3), RepetitionPenaltyLogitsProcessor(1.3)(ids, lp.clone()))
