@@ -17,67 +17,85 @@ def model():
     return PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=tiny_arch(), seed=17, device=DEV)
 
 
-def _margin_equal(got, want, margins, tol=0.1):
-    """identical until the first step whose decision margin is inside bf16 noise (after it the prefixes differ)"""
-    assert got.shape[0] == want.shape[0]
-    checked = 0
-    for b in range(want.shape[0]):
-        for t in range(min(got.shape[1], want.shape[1])):
-            if float(margins[b, t]) < tol:
-                break
-            assert int(got[b, t]) == int(want[b, t]), (b, t)
-            checked += 1
-    return checked
-
-
-def test_greedy_and_beam_match_the_reference_generate(model, golden):
-    """tests/golden/generation.npz: ids from the REFERENCE's own CaptionDecoder.generate (HF generate, K/V cache) on this
-    tiny model.  The HIP path (K/V-cache decode) must return them - same length convention (the prefix embedding counts
-    towards max_length), same EOS / padding behaviour, HF's beam-search rules - wherever the decision margin (from the
-    oracle, teacher-forced) is outside bf16 noise."""
-    import json
-    arch = model.arch
+def _fixture(model, golden):
     g = golden("generation")
-    img = torch.from_numpy(g["images"])
     sd = {k: v.detach().cpu() for k, v in model.store.state_dict(aliases=False).items()}
-    emb = torch.from_numpy(g["embeddings"])
-    pad, eos = int(g["pad"]), int(g["eos"])
-    # first-step logits
-    pv = model.caption_decoder.engine.prefix_embedding(model.vision_encoder(img)["embeddings"])
-    l0 = model.caption_decoder.engine.next_token_logits(pv, torch.zeros(5, 0, dtype=torch.long, device=DEV)).cpu()
-    ref0 = R.generate_step_logits(sd, emb, torch.zeros(5, 0, dtype=torch.long), arch.gpt.heads)
-    assert float((l0 - ref0).abs().max()) <= 5e-2
-    total = 0
-    for name in ("greedy", "greedy_norep"):
+    return g, sd, torch.from_numpy(g["images"]), torch.from_numpy(g["embeddings"]), int(g["pad"]), int(g["eos"])
+
+
+def test_decode_logits_along_the_reference_captions(model, golden):
+    """tests/golden/generation.npz holds ids from the REFERENCE's own CaptionDecoder.generate (HF generate with its K/V
+    cache).  Teacher-forced along those captions, the K/V-cache decode must give the oracle's next-token logits at every
+    position, and the reference's token wherever its margin over the runner-up is outside bf16 noise.  (A free-running
+    comparison says little on this model: its 509 logits have a spread of 0.2 and first-step top-2 gaps of 0.002-0.014.)"""
+    g, sd, img, emb, pad, eos = _fixture(model, golden)
+    arch, eng = model.arch, model.caption_decoder.engine
+    want = torch.from_numpy(g["greedy_norep_ids"])                       # [5, 8], no repetition penalty: raw argmax
+    pv = eng.prefix_embedding(model.vision_encoder(img)["embeddings"])
+    assert float((model.vision_encoder(img)["embeddings"].cpu() - emb).abs().max()) <= 4e-2
+    worst, agree = 0.0, 0
+    for use_graphs in (False, True, True):                               # eager, capture pass, replay pass
+        eng.use_graphs = use_graphs
+        logits = eng.decode_begin(pv, want.shape[1] + 1)
+        for t in range(want.shape[1]):
+            ref = R.generate_step_logits(sd, emb, want[:, :t], arch.gpt.heads)
+            got = logits.cpu()
+            worst = max(worst, float((got - ref).abs().max()))
+            top2 = ref.topk(2, dim=-1).values
+            sure = (top2[:, 0] - top2[:, 1]) >= 0.03
+            assert torch.equal(got.argmax(-1)[sure], want[:, t][sure]), t
+            agree += int(sure.sum())
+            logits = eng.decode_advance(want[:, t].to(DEV))
+    assert worst <= 2e-2, worst
+    assert agree >= 60, agree
+
+
+def test_generation_loop_rules_reproduce_the_reference_generate(model, golden, monkeypatch):
+    """The token-selection logic - HF's length convention (the prefix embedding is one of the max_length positions), EOS
+    and padding, repetition penalty on logits (greedy) or on log-probabilities (beams), HF's beam-search bookkeeping -
+    given EXACT logits: the engine's logits are replaced by the oracle's, and every case of the fixture (greedy, beams,
+    an EOS that occurs) must come out token for token as the reference's generate produced it."""
+    import json
+    g, sd, img, emb, pad, eos = _fixture(model, golden)
+    arch, eng = model.arch, model.caption_decoder.engine
+
+    def oracle_logits(pv, ids):
+        rows = ids.shape[0] // emb.shape[0]
+        return R.generate_step_logits(sd, emb.repeat_interleave(rows, 0), ids.cpu(), arch.gpt.heads).to(DEV)
+    monkeypatch.setattr(eng, "next_token_logits", oracle_logits)
+    for name in ("greedy", "greedy_norep", "beam4", "beam3_rep"):
         kw = json.loads(str(g[name + "_kw"]))
-        want, margins = R.generate_greedy(sd, emb, kw["max_length"], arch.gpt.heads, pad, eos, kw["repetition_penalty"])
-        assert torch.equal(want, torch.from_numpy(g[name + "_ids"]))
-        for cache in (True, False):
-            got = model.generate_token_ids(img, use_cache=cache, **kw).cpu()
-            assert got.shape == want.shape, (name, got.shape, want.shape)
-            total += _margin_equal(got, want, margins)
-    for name in ("beam4", "beam3_rep"):
-        kw = json.loads(str(g[name + "_kw"]))
-        want, gaps = R.generate_beam_search(sd, emb, kw["max_length"], kw["num_beams"], arch.gpt.heads, pad, eos,
-                                            kw["repetition_penalty"])
-        assert torch.equal(want, torch.from_numpy(g[name + "_ids"]))
-        for cache in (True, False):
-            got = model.generate_token_ids(img, use_cache=cache, **kw).cpu()
-            if float(gaps.min()) >= 0.05:      # no candidate ranking anywhere near a tie: the beams must be identical
-                assert torch.equal(got, want), (name, cache)
-                total += want.numel()
-            else:                               # otherwise image by image, up to the first near-tie of that image
-                total += _margin_equal(got, want, gaps.repeat_interleave(1, 0), tol=0.05)
-    assert total >= 60, total
-    # an EOS that occurs: the caption ends there and is padded, the batch keeps going for the others
+        got = model.generate_token_ids(img, use_cache=False, **kw).cpu()
+        assert torch.equal(got, torch.from_numpy(g[name + "_ids"])), name
     e2 = int(g["eos_case_eos"])
     got = model.generate_token_ids(img, max_length=9, num_beams=1, do_sample=False, repetition_penalty=1.0,
-                                   eos_token_id=e2).cpu()
-    want = torch.from_numpy(g["greedy_eos_ids"])
-    wm, margins = R.generate_greedy(sd, emb, 9, arch.gpt.heads, pad, e2, 1.0)
-    assert got.shape == want.shape
-    _margin_equal(got, want, margins)
+                                   eos_token_id=e2, use_cache=False).cpu()
+    assert torch.equal(got, torch.from_numpy(g["greedy_eos_ids"]))
     assert int(got[0, 0]) == e2 and bool((got[0, 1:] == pad).all())
+    got = model.generate_token_ids(img, max_length=8, num_beams=4, do_sample=False, repetition_penalty=1.0,
+                                   eos_token_id=e2, use_cache=False).cpu()
+    assert torch.equal(got, torch.from_numpy(g["beam4_eos_ids"]))
+
+
+def test_cached_and_cache_free_generation_return_the_same_captions(model):
+    """Free-running greedy and beam search, K/V cache against prefix recomputation, on a model whose logits are sharp
+    enough for the comparison to mean something (tied embedding x 12)."""
+    arch = model.arch
+    img = torch.randn(6, 3, arch.vit.image, arch.vit.image, generator=torch.Generator().manual_seed(31))
+    seg = model.store.segments["decoder"]
+    name = "caption_decoder.lm_model.transformer.wte.weight"
+    saved = seg.w(name).clone()
+    try:
+        seg.w(name).mul_(12.0)
+        model.sync_bf16()
+        for kw in (dict(num_beams=1, do_sample=False, repetition_penalty=1.1), dict(num_beams=3, do_sample=False)):
+            a = model.generate_token_ids(img, max_length=14, use_cache=True, **kw)
+            b = model.generate_token_ids(img, max_length=14, use_cache=False, **kw)
+            same = (a == b).float().mean()
+            assert a.shape == b.shape and float(same) >= 0.9, (kw, float(same))
+    finally:
+        seg.w(name).copy_(saved)
+        model.sync_bf16()
 
 
 def test_cache_and_cache_free_decoding_agree(model):
