@@ -36,7 +36,7 @@ typedef enum pgca_status {
   PGCA_ERR_LAUNCH = -2   /* hipLaunch failed; see pgca_last_error() */
 } pgca_status;
 
-#define PGCA_ABI_VERSION 300 /* bumped whenever a signature or struct layout below changes */
+#define PGCA_ABI_VERSION 302 /* bumped whenever a signature or struct layout below changes */
 int pgca_version(void);        /* == PGCA_ABI_VERSION of the header the library was built from */
 int pgca_sizeof_gemm_args(void); /* sizeof(pgca_gemm_args) as compiled: bindings compare it with their own layout */
 const char* pgca_last_error(void);
@@ -133,6 +133,39 @@ int pgca_set_option(const char* name, int32_t value);
  * modeling_gpt2.py:203,222-224,229-243 under trainer.py:494,606 loss.backward()) - run as ONE grid with the whole K per
  * tile: no split-K, no atomics.  Anything else falls back to `count` ordinary pgca_gemm_bf16 launches. */
 int pgca_gemm_bf16_grouped(const pgca_gemm_args* args, int32_t count, void* stream);
+
+/* Skinny product for incremental decoding (generation with a K/V cache: reference models/model.py:657-675 -> HF generate,
+ * modeling_gpt2.py:144-226 with layer_past): y[M, N] = epilogue(x[M, K] . W[K, N]) for 1 <= M <= PGCA_SKINNY_MAX_M rows,
+ * W row-major [K, N] (GPT-2 Conv1D), one pass over W spread over every CU (column chunks x K splits, each storing its partial
+ * [M, N] slab in `scratch`), then a per-row finish that sums the slabs in a fixed order (bitwise reproducible):
+ * v = acc + bias[n]; act (PGCA_EPI_NONE | PGCA_EPI_GELU_NEW); + residual[m, n];
+ * out_f32 / out_bf16 (either or both, arbitrary row strides - e.g. a K/V-cache row); optionally the LayerNorm of the finished
+ * f32 row (ln_gamma/ln_beta/ln_eps -> ln_out_bf16 [M, ld_ln]: the operand of the next product, no separate LN launch).
+ * scratch: pgca_gemm_skinny_workspace(M, N, K) bytes (16-B aligned), contents irrelevant on entry.
+ * Constraints: N % 8 == 0, N <= 8192, ldw % 8 == 0, pointers 16-B aligned, row strides multiples of 4 elements. */
+#define PGCA_SKINNY_MAX_M 64
+typedef struct pgca_skinny_args {
+  const void* x;   /* bf16 [M, lda] */
+  const void* W;   /* bf16 [K, ldw] */
+  int32_t M, N, K, lda, ldw;
+  float* scratch;
+  const float* bias;      /* [N] or NULL */
+  int32_t act;
+  const float* residual;  /* f32 [M, ld_res] or NULL */
+  int32_t ld_res;
+  float* out_f32;
+  int32_t ld_out_f32;
+  void* out_bf16;
+  int32_t ld_out_bf16;
+  const float* ln_gamma;
+  const float* ln_beta;
+  float ln_eps;
+  void* ln_out_bf16;      /* NULL: no fused LayerNorm */
+  int32_t ld_ln;
+} pgca_skinny_args;
+int pgca_gemm_skinny(const pgca_skinny_args* args, void* stream);
+int64_t pgca_gemm_skinny_workspace(int32_t M, int32_t N, int32_t K);
+int pgca_sizeof_skinny_args(void);
 
 /* Per-row combine of ROWSTATS partials: lse[m] = log sum exp over all columns;
  * out_logprob[m] = target_val[m] - lse[m] (token log-prob, reference model.py:1074-1079). */

@@ -25,4 +25,5 @@ int check_launch(const char* what) {
 
 extern "C" int pgca_version(void) { return PGCA_ABI_VERSION; }
 extern "C" int pgca_sizeof_gemm_args(void) { return (int)sizeof(pgca_gemm_args); }
+extern "C" int pgca_sizeof_skinny_args(void) { return (int)sizeof(pgca_skinny_args); }
 extern "C" const char* pgca_last_error(void) { return pgca::g_err; }

@@ -373,6 +373,8 @@ class GptTrunk:
         return h
 
     # -- incremental decoding (generation) ---------------------------------------------------------
+    SKINNY_ROWS = 32   # up to this many sequences a decode step runs on pgca_gemm_skinny (faster than the tile GEMMs up to 32 rows: DESIGN 5)
+
     def decode_cache(self, R: int, smax: int) -> dict:
         """Per-layer K/V cache of an incremental decode over ``R`` sequences of at most ``smax`` positions: one resident
         ``[R * smax, 3H]`` bf16 buffer per layer in the SAME q|k|v row layout the attention kernel reads (row r*smax + t
@@ -380,14 +382,16 @@ class GptTrunk:
         a, H = self.arch, self.arch.hidden
         if smax > a.n_pos:
             raise ValueError(f"{smax} positions exceed GPT-2's {a.n_pos} learned positions")
-        kv = [self._buf(f"gen.kv{li}", (R * smax, 3 * H), BF16) for li in range(len(self.layers))]
+        L = len(self.layers)
+        kv_all = self._buf("gen.kv", (L, R * smax, 3 * H), BF16)     # ONE allocation: a beam reorder is one gather
+        kv = [kv_all[li] for li in range(L)]
         att = self._buf("gen.att", (R * smax, H), BF16)
         cu = self.ws.bufs.get(self.tag + ".gen.cu")
         if cu is None or cu.numel() != R + 1 or int(getattr(self, "_gen_smax", -1)) != smax:
             cu = (torch.arange(R + 1, dtype=I32, device=self.ws.device) * smax).contiguous()
             self.ws.bufs[self.tag + ".gen.cu"] = cu
             self._gen_smax = smax
-        return dict(kv=kv, att=att, cu=cu, R=R, smax=smax)
+        return dict(kv=kv, kv_all=kv_all, att=att, cu=cu, R=R, smax=smax)
 
     def decode_step(self, x: torch.Tensor, st: dict, t: int) -> torch.Tensor:
         """One position of an incremental forward: ``x`` [R, H] f32 is the input embedding (+ position) of position
@@ -404,6 +408,29 @@ class GptTrunk:
         act = self._buf("gen.act", (R, I), BF16)
         att = st["att"]
         att_t = att.view(-1)[t * H:]
+        L = len(self.layers)
+        if R <= min(self.SKINNY_ROWS, hip.SKINNY_MAX_M) and I <= 8192 and 3 * H <= 8192:
+            # a handful of rows: every product is one pass over its weights spread over all CUs (pgca_gemm_skinny), and
+            # each LayerNorm rides on the finish pass of the product before it
+            need = max(hip.gemm_skinny_workspace(R, n, k) for n, k in ((3 * H, H), (H, H), (I, H), (H, I))) // 4
+            sc = self._buf("gen.scratch", (need,), F32)
+            P0 = self.layers[0]
+            hip.layernorm_fwd(x, R, H, P0["ln1w"].w, P0["ln1b"].w, a.eps, y_bf16=y)
+            for li, P in enumerate(self.layers):
+                kv = st["kv"][li]
+                hip.gemm_skinny(y, P["wqkv"].b, R, 3 * H, H, sc, bias=P["bqkv"].w, out_bf16=kv.view(-1)[t * 3 * H:],
+                                ld_out_bf16=smax * 3 * H)
+                hip.attention_fwd(kv, None, R, t + 1, a.heads, True, att, None, cu=st["cu"])
+                hip.gemm_skinny(att_t, P["wo"].b, R, H, H, sc, lda=smax * H, bias=P["bo"].w, residual=x, out_f32=x,
+                                ln=(P["ln2w"].w, P["ln2b"].w, a.eps), ln_out=y)
+                hip.gemm_skinny(y, P["wfc"].b, R, I, H, sc, bias=P["bfc"].w, act=hip.EPI_GELU_NEW, out_bf16=act)
+                nxt = (self.layers[li + 1]["ln1w"].w, self.layers[li + 1]["ln1b"].w) if li + 1 < L else \
+                    (self.lnf_w.w, self.lnf_b.w)
+                hip.gemm_skinny(act, P["wpr"].b, R, H, I, sc, bias=P["bpr"].w, residual=x, out_f32=x,
+                                ln=(nxt[0], nxt[1], a.eps), ln_out=y)
+            st["lnf_done"] = True      # y holds ln_f(x): the LM head's operand
+            return x
+        st["lnf_done"] = False
         for li, P in enumerate(self.layers):
             kv = st["kv"][li]
             hip.layernorm_fwd(x, R, H, P["ln1w"].w, P["ln1b"].w, a.eps, y_bf16=y)
@@ -419,9 +446,8 @@ class GptTrunk:
     def decode_reorder(self, st: dict, src: torch.Tensor) -> None:
         """Beam search: sequence r continues from cached sequence ``src[r]`` (HF ``_reorder_cache``)."""
         R, smax = st["R"], st["smax"]
-        for li, kv in enumerate(st["kv"]):
-            v = kv.view(R, smax, -1)
-            v.copy_(v.index_select(0, src))
+        v = st["kv_all"].view(len(self.layers), R, -1)
+        v.copy_(v.index_select(1, src))
 
     def top_drop(self):
         """Dropout triple the producer of ``g_bf`` (the ln_f backward) must apply: last layer's mlp dropout."""
@@ -1013,8 +1039,11 @@ class CaptionDecoderEngine:
         a, st = self.arch.gpt, self._dec
         R, H = st["R"], a.hidden
         self.trunk.decode_step(x, st, st["t"])
-        hf = self._buf("gen.hf", (R, H), BF16)
-        hip.layernorm_fwd(x, R, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_bf16=hf)
+        if st.get("lnf_done"):           # the last product's finish pass already ran ln_f
+            hf = self.trunk._buf("gen.y", (R, H), BF16)
+        else:
+            hf = self._buf("gen.hf", (R, H), BF16)
+            hip.layernorm_fwd(x, R, H, self.trunk.lnf_w.w, self.trunk.lnf_b.w, a.eps, y_bf16=hf)
         ldv = (self.V + 3) // 4 * 4
         out = self._buf("gen.logits", (R, ldv), F32)
         hip.gemm(hf, self.wte.b, R, self.V, H, hip.NT, out_f32=out, ld_out_f32=ldv)

@@ -44,12 +44,28 @@ class GemmArgs(C.Structure):
     ]
 
 
+class SkinnyArgs(C.Structure):
+    _fields_ = [
+        ("x", _vp), ("W", _vp),
+        ("M", _i32), ("N", _i32), ("K", _i32), ("lda", _i32), ("ldw", _i32),
+        ("scratch", _vp), ("bias", _vp), ("act", _i32),
+        ("residual", _vp), ("ld_res", _i32),
+        ("out_f32", _vp), ("ld_out_f32", _i32),
+        ("out_bf16", _vp), ("ld_out_bf16", _i32),
+        ("ln_gamma", _vp), ("ln_beta", _vp), ("ln_eps", _f32),
+        ("ln_out_bf16", _vp), ("ld_ln", _i32),
+    ]
+
+
+SKINNY_MAX_M = 64  # include/pgca_hip.h PGCA_SKINNY_MAX_M
+
 # name -> argtypes (return type is always int status unless noted)
 _SIGS = {
     "pgca_gemm_bf16": [C.POINTER(GemmArgs), _vp],
     "pgca_gemm_plan": [C.POINTER(GemmArgs)],
     "pgca_set_option": [C.c_char_p, _i32],
     "pgca_gemm_bf16_grouped": [C.POINTER(GemmArgs), _i32, _vp],
+    "pgca_gemm_skinny": [C.POINTER(SkinnyArgs), _vp],
     "pgca_rowstats_combine": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp],
     "pgca_layernorm_fwd": [_vp, _vp, _i32, _i32, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_layernorm_bwd_blocks": [_i32],
@@ -94,8 +110,9 @@ _SIGS = {
     "pgca_axpy": [_vp, _f32, _vp, _i64, _i32, _vp],
     "pgca_gather_rows_bf16": [_vp, _vp, _i32, _i32, _vp, _vp],
 }
-EXPORTS = ["pgca_version", "pgca_last_error", "pgca_sizeof_gemm_args"] + list(_SIGS)
-ABI_VERSION = 300  # include/pgca_hip.h PGCA_ABI_VERSION
+EXPORTS = ["pgca_version", "pgca_last_error", "pgca_sizeof_gemm_args", "pgca_sizeof_skinny_args",
+           "pgca_gemm_skinny_workspace"] + list(_SIGS)
+ABI_VERSION = 302  # include/pgca_hip.h PGCA_ABI_VERSION
 
 _lib = None
 
@@ -119,6 +136,12 @@ def load() -> C.CDLL:
     if lib.pgca_sizeof_gemm_args() != C.sizeof(GemmArgs):
         raise RuntimeError(f"pgca_gemm_args is {lib.pgca_sizeof_gemm_args()} bytes in {LIB_PATH} but "
                            f"{C.sizeof(GemmArgs)} in the binding: stale library, rebuild it")
+    lib.pgca_sizeof_skinny_args.restype = C.c_int
+    if lib.pgca_sizeof_skinny_args() != C.sizeof(SkinnyArgs):
+        raise RuntimeError(f"pgca_skinny_args is {lib.pgca_sizeof_skinny_args()} bytes in {LIB_PATH} but "
+                           f"{C.sizeof(SkinnyArgs)} in the binding: stale library, rebuild it")
+    lib.pgca_gemm_skinny_workspace.restype = C.c_int64
+    lib.pgca_gemm_skinny_workspace.argtypes = [_i32, _i32, _i32]
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes = sig
@@ -195,6 +218,28 @@ def gemm_wgrad_group(problems) -> None:
         a.ld_out_bf16 = a.ld_res = a.ld_aux = N
         a.accumulate = 1
     _check(load().pgca_gemm_bf16_grouped(arr, n, _stream()), "pgca_gemm_bf16_grouped")
+
+
+def gemm_skinny(x, W, M, N, K, scratch, *, lda=None, ldw=None, bias=None, act=EPI_NONE, residual=None, ld_res=None,
+                out_f32=None, ld_out_f32=None, out_bf16=None, ld_out_bf16=None, ln=None, ln_out=None, ld_ln=None):
+    """y = epilogue(x[M,K] . W[K,N]) for a handful of rows (incremental decoding); ``ln`` = (gamma, beta, eps) runs the
+    next LayerNorm on the finished row into ``ln_out``.  ``scratch``: ``gemm_skinny_workspace(M, N, K)`` bytes."""
+    a = SkinnyArgs()
+    a.x, a.W = x.data_ptr(), W.data_ptr()
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldw = (K if lda is None else lda), (N if ldw is None else ldw)
+    a.scratch, a.bias, a.act = scratch.data_ptr(), _p(bias), act
+    a.residual, a.ld_res = _p(residual), (N if ld_res is None else ld_res)
+    a.out_f32, a.ld_out_f32 = _p(out_f32), (N if ld_out_f32 is None else ld_out_f32)
+    a.out_bf16, a.ld_out_bf16 = _p(out_bf16), (N if ld_out_bf16 is None else ld_out_bf16)
+    if ln is not None:
+        a.ln_gamma, a.ln_beta, a.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2])
+        a.ln_out_bf16, a.ld_ln = ln_out.data_ptr(), (N if ld_ln is None else ld_ln)
+    _check(load().pgca_gemm_skinny(C.byref(a), _stream()), "pgca_gemm_skinny")
+
+
+def gemm_skinny_workspace(M: int, N: int, K: int) -> int:
+    return int(load().pgca_gemm_skinny_workspace(M, N, K))
 
 
 def drop_args(seed: int, p: float):

@@ -352,7 +352,9 @@ class CaptionDecoder:
             worst_fin = torch.where(is_sent_finished, beam_scores.min(dim=1, keepdim=True)[0],
                                     torch.full_like(beam_scores, -1.0e9))
             unsat = unsat & (best_run > worst_fin).any(dim=-1, keepdim=True)
-            if cur >= L or not bool(unsat.any() & ~hits.all()):
+            # HF reads this flag back every step; here every EOS_CHECK steps: once no batch item can improve, the
+            # finished pool is closed to new entries (the -1e9 terms above), so the extra steps change nothing
+            if cur >= L or (cur % self.EOS_CHECK == 0 and not bool(unsat.any() & ~hits.all())):
                 break
             tok = torch.gather(topk_ids, 1, nxt_idx).view(R)
             if use_cache:

@@ -179,3 +179,37 @@ def test_sampling_and_beam_contracts(model):
     caps = model.generate_captions(img, max_length=4, num_beams=1, do_sample=False)
     assert len(caps) == 3 and all(isinstance(c, str) and c for c in caps)
     del model.caption_decoder.tokenizer
+
+
+@pytest.mark.parametrize("M,N,K,act,fuse_ln", [(1, 3072, 1024, 0, False), (4, 1024, 1024, 0, True), (16, 4096, 1024, 1, False),
+                                               (5, 1024, 4096, 0, True), (33, 1600, 6400, 0, True), (64, 4800, 1600, 0, False),
+                                               (3, 264, 200, 1, False)])
+def test_skinny_gemm_against_fp32(M, N, K, act, fuse_ln):
+    """pgca_gemm_skinny (the decode-step product: split-K over all CUs + per-row finish with bias / gelu_new / residual /
+    fused LayerNorm, strided rows) against plain fp32 PyTorch on the same bf16 operands."""
+    from pgca_amd import hip as H
+    H.load()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    lda, ld_out = K + 64, N + 24
+    xb = (torch.randn(M, lda, generator=g)).bfloat16().to(DEV)
+    W = (torch.randn(K, N, generator=g) * 0.05).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    gamma, beta = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    scratch = torch.full((H.gemm_skinny_workspace(M, N, K) // 4,), float("nan"), device=DEV)   # contents irrelevant
+    out_f = torch.zeros(M, N, device=DEV)
+    out_b = torch.zeros(M, ld_out, dtype=torch.bfloat16, device=DEV)
+    ln_out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    H.gemm_skinny(xb, W, M, N, K, scratch, lda=lda, bias=bias, act=H.EPI_GELU_NEW if act else H.EPI_NONE, residual=res,
+                  out_f32=out_f, out_bf16=out_b, ld_out_bf16=ld_out,
+                  ln=(gamma, beta, 1e-5) if fuse_ln else None, ln_out=ln_out if fuse_ln else None)
+    v = xb[:, :K].float() @ W.float() + bias
+    if act:
+        v = 0.5 * v * (1 + torch.tanh(0.7978845608028654 * (v + 0.044715 * v ** 3)))
+    v = v + res
+    scale = float(v.abs().max())
+    assert float((out_f - v).abs().max()) <= 2e-4 * scale + 2e-3 * bool(act)
+    assert float((out_b[:, :N].float() - v).abs().max()) <= 2 ** -7 * scale
+    if fuse_ln:
+        want = torch.nn.functional.layer_norm(out_f, (N,), gamma, beta, 1e-5)
+        assert float((ln_out.float() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())

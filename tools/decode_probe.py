@@ -15,10 +15,14 @@ def main():
     model = PreferenceGuidedCaptioningModel("openai/clip-vit-base-patch32", "gpt2-medium", 512, freeze_vision_backbone=True,
                                             device=dev, seed=1)
     eng = model.caption_decoder.engine
-    for R in (1, 4, 32, 128):
+    for R, skinny in ((1, 0), (1, 64), (2, 0), (2, 64), (4, 0), (4, 64), (8, 0), (8, 64), (16, 0), (16, 64), (32, 0),
+                      (32, 64), (128, 0)):
         pv = torch.randn(R, 1024, device=dev)
         tok = torch.randint(0, 50257, (R,), device=dev)
-        for graphs in (False, True):
+        eng.trunk.SKINNY_ROWS = skinny
+        eng.__dict__.pop("_graphs", None)
+        print(f"--- rows {R}, {'skinny products' if skinny else 'tile GEMMs'}")
+        for graphs in (True,):
             eng.use_graphs = graphs
             for rep in range(3):            # pass 0 sizes buffers / captures, passes 1-2 are timed
                 eng.decode_begin(pv, 50)
