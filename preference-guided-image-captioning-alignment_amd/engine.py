@@ -446,7 +446,7 @@ class GptTrunk:
     def decode_reorder(self, st: dict, src: torch.Tensor) -> None:
         """Beam search: sequence r continues from cached sequence ``src[r]`` (HF ``_reorder_cache``)."""
         R, smax = st["R"], st["smax"]
-        v = st["kv_all"].view(len(self.layers), R, -1)
+        v = st["kv_all"].view(len(self.layers), R, smax, -1)[:, :, :st.get("t", smax - 1) + 1]   # the filled positions
         v.copy_(v.index_select(1, src))
 
     def top_drop(self):
