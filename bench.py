@@ -107,24 +107,32 @@ def cpu_baseline(model, arch, S, beta, pairs):
             v.grad = None
         return float(loss)
 
+    # B = 8, one warm-up then three timed optimizer-free steps.  The warm-up runs on ONE pair (it is
+    # there to page in the weights and the allocator, which one pair does), so the whole leg stays near 25-30 s of host time
     full = b
     b = {k: v[:1] for k, v in full.items()}
-    step()  # untimed one-pair pass: pages in the weights and the allocator
-    b = full
-    t0 = time.time()
     step()
-    dt = time.time() - t0
+    b = full
+    times = []
+    for _ in range(3):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    dt = sum(times) / len(times)
     return {"value": pairs / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 optimizer-free 4-forward DPO step (fwd+bwd), {pairs} pairs, S={S}, fp32, full depth, "
-                      f"oracle/restatement.py; {dt:.1f} s"}
+            "sample": f"3 timed optimizer-free 4-forward DPO steps (fwd+bwd) of {pairs} pairs after a 1-pair warm-up, S={S}, "
+                      f"fp32, full depth, oracle/restatement.py; {', '.join(f'{t:.1f}' for t in times)} s"}
+
+
+PMC_FILE = "profiles/r03_pmc_summary.json"
 
 
 def pmc_from_profile(pairs_per_gpu: int, kernel_substr: str):
-    """HBM bytes per launch and matrix-pipe busy fraction of the dominant kernel from the committed rocprofv3 PMC passes
-    of THIS command (profiles/r02_pmc_summary.json, made by tools/pmc_summary.py: the counters cannot be collected from
-    inside the process, and FETCH_SIZE / WRITE_SIZE need separate passes).  Only reported for the workload the passes were
-    taken on."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_summary.json")
+    """HBM bytes per launch and matrix-pipe busy fraction of the dominant kernel from COMMITTED rocprofv3 PMC passes of this
+    command (made by tools/pmc_summary.py: the counters cannot be collected from inside the process, and FETCH_SIZE /
+    WRITE_SIZE need separate passes).  They are NOT measured in this run: the line says which file and which commit they
+    come from, and they are only reported for the workload the passes were taken on."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), PMC_FILE)
     try:
         with open(path) as fh:
             d = json.load(fh)
@@ -221,7 +229,7 @@ def main():
     ap.add_argument("--text-model", default="gpt2-medium")
     ap.add_argument("--reference-free", action="store_true", help="2-forward trainer path instead of 4-forward DPO")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=16)
+    ap.add_argument("--cpu-pairs", type=int, default=8, help="pairs per CPU-baseline step (BASELINE.md section 3: 8)")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.1, help="train-mode dropout of the policy (reference: 0.1)")
     ap.add_argument("--with-input-path", action="store_true",
@@ -458,9 +466,12 @@ def main():
                                "frac": ps["tflops"] / PEAK_BF16_TFLOPS,
                                "traffic": pmc.get("hbm_bytes") if pmc else None,
                                "mfma_busy": pmc.get("mfma_busy") if pmc else None,
-                               "traffic_note": "HBM-side bytes per launch (read = 2 x FETCH_SIZE on gfx950, + WRITE_SIZE) and matrix-pipe "
-                                               "busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x SQ_BUSY_CYCLES / 32)) from "
-                                               "separate rocprofv3 --pmc passes of this command: profiles/r02_pmc_summary.json",
+                               "traffic_note": ("NOT measured in this run: HBM-side bytes per launch (read = 2 x FETCH_SIZE on gfx950, + "
+                                                "WRITE_SIZE) and matrix-pipe busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                                                f"SQ_BUSY_CYCLES / 32)) copied from the committed rocprofv3 --pmc passes of this command, "
+                                                f"{PMC_FILE}" + (f" (taken at commit {pmc.get('commit')})" if pmc and pmc.get("commit")
+                                                                 else "")) if pmc else
+                               f"null: no committed PMC passes for this workload ({PMC_FILE})",
                                "kernel": "gemm256s_kernel<0, 1> (every launch of the NN 256x256 LDS-DMA GEMM, phase-staggered schedule, in the timed steps)", "launches": ps["launches"],
                                "avg_launch_us": ps["avg_us"]}
         if ps and dp.world == 1:

@@ -321,11 +321,13 @@ int pgca_seq_batch_prepare(const int64_t* ids, const int64_t* mask, int32_t Bq, 
 /* Packed (variable-length) row layout of a right-padded batch: only positions t < len[b] = 1 + (last t with mask[b,t] != 0)
  * are given a row, sequence after sequence (reference semantics: with a causal AND key-padding mask, a masked mean and a
  * masked loss - model.py:449-456,1069-1083, SURVEY 3.1 items 6-7 - nothing a padded position computes reaches a loss term or
- * a gradient).  mask32 int32 [Bq+1, S]: rows 0..Bq-1 as written by pgca_seq_batch_prepare; row Bq is SET TO ONES here.
+ * a gradient).  With F = ceil((pad_to - 1) / S) filler pseudo-sequences (1 whenever S >= pad_to - 1):
+ * mask32 int32 [Bq+F, S]: rows 0..Bq-1 as written by pgca_seq_batch_prepare; rows Bq.. are SET TO ONES here.
  *   lens[Bq]: the packed length of every sequence;
- *   cu[Bq+2]: cu[b] = first row of sequence b, cu[Bq] = n = sum len, cu[Bq+1] = n rounded up to a multiple of pad_to;
- *             rows cu[Bq]..cu[Bq+1]-1 are filler (an extra unmasked "sequence" of zero embeddings) that keeps the row
- *             count a multiple of the GEMM K tile for the weight gradients;
+ *   cu[Bq+F+1]: cu[b] = first row of sequence b, cu[Bq] = n = sum len, cu[Bq+F] = n rounded up to a multiple of pad_to;
+ *             rows cu[Bq]..cu[Bq+F]-1 are filler (extra unmasked "sequences" of zero embeddings, at most S rows each so
+ *             that they obey the attention kernels' length bound) that keeps the row count a multiple of the GEMM K
+ *             tile for the weight gradients;
  *   row_ids[cap]: row_ids[cu[b] + t] = b*S + t; filler rows get -1  (cap >= Bq*S rounded up to pad_to);
  *   n_packed[2] = {n, n rounded up};
  *   row_map (optional, in place, with counts from pgca_seq_batch_prepare): b*S + t  ->  cu[b] + t for the compact rows. */

@@ -41,8 +41,49 @@ class Config:
                 raise ValueError(f"Missing required configuration section: training.{st}")
         self._apply_env_overrides()
 
+    # the reference's own environment overrides (utils/config.py:91-136), same names, same targets
+    REFERENCE_ENV = {
+        "CONCEPTUAL_CAPTIONS_PATH": "data.conceptual_captions_path", "ULTRAFEEDBACK_PATH": "data.ultrafeedback_path",
+        "CAPTION_ALIGNMENT_DATA_DIR": "data.conceptual_captions_path",
+        "OUTPUT_DIR": "paths.output_dir", "CACHE_DIR": "paths.cache_dir",
+        "CAPTION_ALIGNMENT_CACHE_DIR": "paths.cache_dir", "CAPTION_ALIGNMENT_OUTPUT_DIR": "paths.output_dir",
+        "CAPTION_ALIGNMENT_LOG_DIR": "paths.log_dir",
+        "CAPTION_ALIGNMENT_VISION_MODEL": "model.vision_model", "CAPTION_ALIGNMENT_TEXT_MODEL": "model.text_model",
+        "CAPTION_ALIGNMENT_DEVICE": "hardware.device",
+        "CAPTION_ALIGNMENT_BATCH_SIZE": "training.stage1.batch_size",
+        "CAPTION_ALIGNMENT_LEARNING_RATE": "training.stage1.learning_rate",
+        "CAPTION_ALIGNMENT_NUM_EPOCHS": "training.stage1.num_epochs", "CAPTION_ALIGNMENT_LOG_LEVEL": "logging.level",
+        "WANDB_PROJECT": "logging.wandb_project", "WANDB_ENTITY": "logging.wandb_entity",
+        "MLFLOW_EXPERIMENT": "logging.mlflow_experiment", "MLFLOW_TRACKING_URI": "logging.mlflow_tracking_uri",
+        "CAPTION_ALIGNMENT_NUM_WORKERS": "data.num_workers", "CAPTION_ALIGNMENT_PIN_MEMORY": "data.pin_memory",
+        "CAPTION_ALIGNMENT_MIXED_PRECISION": "hardware.mixed_precision",
+    }
+
+    @staticmethod
+    def _convert_env_value(value: str) -> Any:
+        """The reference's conversion (utils/config.py:151-182): booleans by name, then int, then float, else the string."""
+        low = value.lower()
+        if low in ("true", "1", "yes", "on"):
+            return True
+        if low in ("false", "0", "no", "off"):
+            return False
+        try:
+            if "." not in value and "e" not in low:
+                return int(value)
+        except ValueError:
+            pass
+        try:
+            return float(value)
+        except ValueError:
+            return value
+
     def _apply_env_overrides(self) -> None:
-        """``PGCA_<SECTION>__<KEY>[__<SUBKEY>]=value`` overrides a leaf (values parsed as YAML scalars)."""
+        """The reference's variables (``REFERENCE_ENV``: an empty value is ignored, as there), then this build's generic
+        ``PGCA_CFG_<SECTION>__<KEY>[__<SUBKEY>]=value`` form (values parsed as YAML scalars)."""
+        for name, path in self.REFERENCE_ENV.items():
+            v = os.getenv(name)
+            if v:
+                self.set(path, self._convert_env_value(v))
         for k, v in os.environ.items():
             if not k.startswith("PGCA_CFG_"):
                 continue

@@ -242,16 +242,16 @@ __global__ void seq_pack_kernel(const int* __restrict__ lens, int Bq, int S, int
     off += __shfl_xor(off, o);
     coff += __shfl_xor(coff, o);
   }
-  if (b == Bq) {  // filler: rows off .. padded-1, an unmasked pseudo-sequence
+  if (b == Bq) {  // filler: rows off .. padded-1, as F unmasked pseudo-sequences of at most S rows each
     const int padded = (off + pad_to - 1) / pad_to * pad_to;
+    const int F = (pad_to - 1 + S - 1) / S;
     if (lane == 0) {
-      cu[Bq] = off;
-      cu[Bq + 1] = padded;
+      for (int f = 0; f <= F; ++f) cu[Bq + f] = min(off + f * S, padded);
       n_packed[0] = off;
       n_packed[1] = padded;
     }
     for (int r = off + lane; r < padded; r += 64) row_ids[r] = -1;
-    for (int t = lane; t < S; t += 64) mask32[(size_t)Bq * S + t] = 1;
+    for (int t = lane; t < F * S; t += 64) mask32[(size_t)Bq * S + t] = 1;
     return;
   }
   if (lane == 0) cu[b] = off;

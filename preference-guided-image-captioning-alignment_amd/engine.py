@@ -125,14 +125,24 @@ class RowPack:
     key-padding mask, masked mean, masked loss: reference model.py:449-456,1069-1083), so the
     trunk runs on these rows only.  Positions, key masks, log-sum-exps and every dropout index stay keyed on the padded
     (b, t), so a packed launch reproduces the padded one token for token."""
-    cu: torch.Tensor        # [Bq+2] int32: first row of each sequence; cu[Bq] = n, cu[Bq+1] = Mp (the filler "sequence")
+    cu: torch.Tensor        # [nseq+1] int32: first row of each sequence; cu[Bq] = n, cu[nseq] = Mp (filler "sequences")
     row_ids: torch.Tensor   # [Mp] int32: padded position b*S + t of each row, -1 for filler rows
-    mask: torch.Tensor      # [Bq+1, S] int32 key mask; the extra last row (the filler's) is ones
+    mask: torch.Tensor      # [nseq, S] int32 key mask; the extra rows (the filler's) are ones
     lens: torch.Tensor      # [Bq] int32
     n: int                  # rows that hold a token
     Mp: int                 # rows incl. filler (multiple of PACK_PAD)
     Bq: int
     S: int
+
+    @property
+    def nseq(self) -> int:
+        """Sequences of an attention launch over the packed rows: the batch's plus the filler pseudo-sequences (at most
+        S rows each, so they obey the kernels' length bound)."""
+        return self.Bq + n_filler_seqs(self.S)
+
+
+def n_filler_seqs(S: int) -> int:
+    return (PACK_PAD - 1 + S - 1) // S
 
 
 @dataclass
@@ -174,7 +184,7 @@ def _issue_pack(mask1: torch.Tensor, Bq: int, S: int, counts=None, row_map=None)
     dev = mask1.device
     cap = (Bq * S + PACK_PAD - 1) // PACK_PAD * PACK_PAD
     lens = torch.empty(Bq, dtype=I32, device=dev)
-    cu = torch.empty(Bq + 2, dtype=I32, device=dev)
+    cu = torch.empty(Bq + n_filler_seqs(S) + 1, dtype=I32, device=dev)
     row_ids = torch.empty(cap, dtype=I32, device=dev)
     n_dev = torch.empty(2, dtype=I32, device=dev)
     hip.seq_pack_prepare(mask1, Bq, S, PACK_PAD, lens, cu, row_ids, n_dev, counts=counts, row_map=row_map)
@@ -184,7 +194,7 @@ def _issue_pack(mask1: torch.Tensor, Bq: int, S: int, counts=None, row_map=None)
 def prepare_row_pack_async(mask32: torch.Tensor) -> PendingRowPack:
     """mask32 [Bq, S] int32 on the device (0/1) -> the packed row layout (Stage 1: no log-prob index work)."""
     Bq, S = mask32.shape
-    mask1 = torch.empty(Bq + 1, S, dtype=I32, device=mask32.device)
+    mask1 = torch.empty(Bq + n_filler_seqs(S), S, dtype=I32, device=mask32.device)
     mask1[:Bq].copy_(mask32)
     lens, cu, row_ids, n_dev = _issue_pack(mask1, Bq, S)
     n_host = torch.empty(2, dtype=I32, pin_memory=True)
@@ -235,7 +245,7 @@ def prepare_seq_batch_async(ids: torch.Tensor, mask: torch.Tensor, device, pack:
     if S < 2:
         raise ValueError("sequences need at least 2 positions (the first token is never scored)")
     cap = Bq * (S - 1)
-    mask1 = torch.empty(Bq + 1, S, dtype=I32, device=dev)   # + the key-mask row of the packed layout's filler
+    mask1 = torch.empty(Bq + n_filler_seqs(S), S, dtype=I32, device=dev)   # + the key-mask rows of the packed filler
     counts = torch.empty(Bq, dtype=I32, device=dev)
     row_map = torch.empty(cap, dtype=I32, device=dev)
     targets = torch.empty(cap, dtype=I64, device=dev)
@@ -333,7 +343,7 @@ class GptTrunk:
         cu = rows = None
         nseq = Bq
         if pack is not None:   # the filler rows are one more (unmasked) sequence of the attention launch
-            M, cu, rows, mask, nseq = pack.Mp, pack.cu, pack.row_ids, pack.mask, Bq + 1
+            M, cu, rows, mask, nseq = pack.Mp, pack.cu, pack.row_ids, pack.mask, pack.nseq
         L = len(self.layers)
         sv = {"M": M, "Bq": Bq, "S": S, "mask": mask, "drop": drop, "pack": pack} if save else None
         dsite = (lambda li, kind: drop(li, kind)) if drop is not None else (lambda li, kind: None)
@@ -468,7 +478,7 @@ class GptTrunk:
         a, H, I = self.arch, self.arch.hidden, self.arch.inner
         M, Bq, S = sv["M"], sv["Bq"], sv["S"]
         pack: Optional[RowPack] = sv.get("pack")
-        cu, rows, nseq = (pack.cu, pack.row_ids, Bq + 1) if pack is not None else (None, None, Bq)
+        cu, rows, nseq = (pack.cu, pack.row_ids, pack.nseq) if pack is not None else (None, None, Bq)
         ws = self.ws
         nb = hip.layernorm_bwd_blocks(M)
         part4 = ws.get("ln_part", (4, nb, H), F32)   # planes: dgamma, dbeta, sum(add_to), sum(dx_out)

@@ -162,10 +162,10 @@ class PreferenceGuidedTrainer:
         self.model.eval()
         tot = torch.zeros(2, dtype=torch.float32, device=self.device)
         for batch in self._feed(loader, prepare):
-            loss = loss_only(batch)
-            if bool(torch.isfinite(loss)):
-                tot[0] += loss.reshape(())
-                tot[1] += 1
+            loss = loss_only(batch).reshape(())
+            ok = torch.isfinite(loss)                       # decided on the device: no read-back per batch
+            tot[0] += torch.where(ok, loss, torch.zeros_like(loss))
+            tot[1] += ok.to(tot.dtype)
         self.dp.all_reduce_sum(tot)  # the reference logs rank 0's value only; here every rank agrees
         return float(tot[0] / tot[1]) if float(tot[1]) > 0 else float("inf")
 

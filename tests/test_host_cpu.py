@@ -38,6 +38,23 @@ def test_config_env_override(tmp_path, monkeypatch):
     assert c.get("training.stage2.dpo_beta") == 0.25
 
 
+def test_reference_environment_overrides(monkeypatch):
+    """The reference's own variables (utils/config.py:91-136) with its value conversion (:151-182)."""
+    for k, v in (("CAPTION_ALIGNMENT_BATCH_SIZE", "16"), ("CAPTION_ALIGNMENT_LEARNING_RATE", "3e-5"),
+                 ("OUTPUT_DIR", "/tmp/run7"), ("CAPTION_ALIGNMENT_PIN_MEMORY", "off"),
+                 ("CAPTION_ALIGNMENT_MIXED_PRECISION", "bf16"), ("CAPTION_ALIGNMENT_VISION_MODEL", "openai/clip-vit-large-patch14"),
+                 ("ULTRAFEEDBACK_PATH", "")):
+        monkeypatch.setenv(k, v)
+    c = Config(os.path.join(REPO_ROOT, "configs", "default.yaml"))
+    assert c.get("training.stage1.batch_size") == 16 and c.get("training.stage1.learning_rate") == 3e-5
+    assert c.get("paths.output_dir") == "/tmp/run7" and c.get("data.pin_memory") is False
+    assert c.get("hardware.mixed_precision") == "bf16"
+    assert c.get("model.vision_model") == "openai/clip-vit-large-patch14"
+    base = Config.__new__(Config)
+    assert Config._convert_env_value("yes") is True and Config._convert_env_value("7") == 7
+    assert Config._convert_env_value("0.5") == 0.5 and Config._convert_env_value("cuda:1") == "cuda:1"
+
+
 def test_parameter_counts_match_reference_readme():
     """README.md:140,179 / SURVEY 6: 867 M total parameters, reproduced as 867 100 417 with the reference's
     modules.  Our store leaves out what the hot path never touches: the CLIP *text* tower and its projections

@@ -134,3 +134,60 @@ def test_components_contrastive_loss_product_side():
     sim = TemperatureScaledSimilarity(temperature=0.01)(v.to(DEV), t.to(DEV)).cpu()
     ref = F.normalize(v, dim=-1) @ F.normalize(t, dim=-1).t() / 0.1
     np.testing.assert_allclose(sim.numpy(), ref.numpy(), atol=2e-4)
+
+
+def cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-300))
+
+
+def test_learnable_temperature_gradient_and_clamp():
+    """components.py:48-57,73-83: ``learnable=True`` makes tau an nn.Parameter; its gradient through
+    ``loss = NT-Xent(cos / clamp(tau))`` against torch autograd on the host; outside the clamp range the gradient is 0."""
+    from pgca_amd.components import ContrastiveLoss as CLoss, TemperatureScaledSimilarity
+    g = torch.Generator().manual_seed(9)
+    v, t = torch.randn(10, 64, generator=g), torch.randn(10, 64, generator=g)
+    for tau0, reduction in ((0.5, "mean"), (0.3, "sum"), (0.05, "mean")):
+        loss_fn = CLoss(temperature=tau0, reduction=reduction)
+        loss_fn.similarity = TemperatureScaledSimilarity(temperature=tau0, learnable=True).to(DEV)
+        vd, td = v.to(DEV).requires_grad_(), t.to(DEV).requires_grad_()
+        loss = loss_fn(vd, td)
+        loss.backward()
+        tau = torch.tensor(tau0, requires_grad=True)
+        vh, th = v.clone().requires_grad_(), t.clone().requires_grad_()
+        sim = F.normalize(vh, dim=-1) @ F.normalize(th, dim=-1).t() / torch.clamp(tau, 0.1, 2.0)
+        lab = torch.arange(10)
+        want = (F.cross_entropy(sim, lab) + F.cross_entropy(sim.t(), lab)) / 2 * (10.0 if reduction == "sum" else 1.0)
+        want.backward()
+        assert abs(float(loss) - float(want)) <= 2e-4 * max(1.0, abs(float(want)))
+        gt = float(loss_fn.similarity.temperature.grad)
+        assert abs(gt - float(tau.grad)) <= 2e-3 * max(1e-3, abs(float(tau.grad))) + 1e-6, (tau0, gt, float(tau.grad))
+        assert cos(vd.grad.cpu(), vh.grad) >= 0.9999
+    sim = TemperatureScaledSimilarity(temperature=0.7, learnable=True).to(DEV)
+    out = sim(v.to(DEV), t.to(DEV))
+    out.sum().backward()
+    ref_t = torch.tensor(0.7, requires_grad=True)
+    (F.normalize(v, dim=-1) @ F.normalize(t, dim=-1).t() / ref_t).sum().backward()
+    assert abs(float(sim.temperature.grad) - float(ref_t.grad)) <= 1e-3 * abs(float(ref_t.grad))
+
+
+def test_nan_safe_gradient_norm_surface():
+    """Reference NaNSafeGradientNorm (components.py:252-318): (total_norm, is_finite); clips only when finite."""
+    from pgca_amd.components import NaNSafeGradientNorm
+    g = torch.Generator().manual_seed(4)
+    ps = [torch.nn.Parameter(torch.zeros(n, device=DEV)) for n in (1000, 37, 70001)]
+    grads = [torch.randn(p.numel(), generator=g) * 3 for p in ps]
+    for p, gr in zip(ps, grads):
+        p.grad = gr.to(DEV).clone()
+    total, ok = NaNSafeGradientNorm(max_norm=1.0)(ps)
+    want = torch.sqrt(sum((gr.double() ** 2).sum() for gr in grads))
+    assert ok and abs(float(total) - float(want)) <= 1e-4 * float(want)
+    after = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in ps))
+    assert abs(float(after) - 1.0) <= 1e-4
+    ps[1].grad[3] = float("nan")
+    before = ps[0].grad.clone()
+    total, ok = NaNSafeGradientNorm(max_norm=1.0)(ps)
+    assert not ok and not bool(torch.isfinite(total)) and torch.equal(ps[0].grad, before)      # untouched
+    with pytest.raises(RuntimeError, match="Non-finite"):
+        NaNSafeGradientNorm(max_norm=1.0, error_if_nonfinite=True)(ps)
+    assert NaNSafeGradientNorm()([torch.nn.Parameter(torch.zeros(3))]) [1] is True                # nothing has a gradient

@@ -41,7 +41,7 @@ def ragged_mask(B, S, lens, holes=()):
     (256, [64] * 4, ()),                                    # row count already a multiple of the pad: no filler
 ])
 def test_row_pack_indices_bit_exact(hip, S, lens, holes):
-    from pgca_amd.engine import PACK_PAD, make_seq_batch
+    from pgca_amd.engine import PACK_PAD, make_seq_batch, n_filler_seqs
     B = len(lens)
     g = torch.Generator().manual_seed(5)
     ids = torch.randint(0, 1000, (B, S), generator=g)
@@ -57,10 +57,13 @@ def test_row_pack_indices_bit_exact(hip, S, lens, holes):
     Mp = (n + PACK_PAD - 1) // PACK_PAD * PACK_PAD
     assert pk.n == n and pk.Mp == Mp and pk.Mp % PACK_PAD == 0
     assert np.array_equal(pk.lens.cpu().numpy(), want_len)
-    assert np.array_equal(pk.cu.cpu().numpy(), np.concatenate([cu, [Mp]]))
+    F = n_filler_seqs(S)
+    assert F == (1 if S >= 63 else -(-63 // S)) and pk.nseq == B + F
+    fill = [min(n + f * S, Mp) for f in range(1, F + 1)]         # filler pseudo-sequences of at most S rows each
+    assert np.array_equal(pk.cu.cpu().numpy(), np.concatenate([cu, fill]))
     rid = np.concatenate([b * S + np.arange(want_len[b]) for b in range(B)] + [np.full(Mp - n, -1)])
     assert np.array_equal(pk.row_ids.cpu().numpy(), rid)
-    assert torch.equal(pk.mask[:B].cpu(), mask.int()) and bool((pk.mask[B] == 1).all())
+    assert torch.equal(pk.mask[:B].cpu(), mask.int()) and bool((pk.mask[B:] == 1).all())
     # the scored rows: same (b, t), renumbered
     rm = sb.row_map.cpu().numpy()
     b_of, t_of = rm // S, rm % S
@@ -70,7 +73,8 @@ def test_row_pack_indices_bit_exact(hip, S, lens, holes):
 
 # ------------------------------------------------------------------------------------------------- attention
 @pytest.mark.parametrize("S,heads,lens,p", [(128, 4, [128, 40, 77, 16, 1], 0.0), (128, 2, [100, 33, 128], 0.1),
-                                            (256, 2, [256, 130, 77, 200], 0.1), (384, 1, [300, 129, 5], 0.0)])
+                                            (256, 2, [256, 130, 77, 200], 0.1), (384, 1, [300, 129, 5], 0.0),
+                                            (16, 2, [16, 3, 9, 1, 12], 0.1)])   # S < 63: several filler sequences
 def test_packed_attention_equals_padded(hip, S, heads, lens, p):
     from pgca_amd.engine import make_row_pack
     B, H = len(lens), heads * 64
@@ -90,10 +94,10 @@ def test_packed_attention_equals_padded(hip, S, heads, lens, p):
     dout_p = torch.zeros(pk.Mp, H, dtype=torch.bfloat16, device=dev())
     qkv_p[:pk.n], dout_p[:pk.n] = qkv[rows], dout[rows]
     out_p = torch.full((pk.Mp, H), float("nan"), dtype=torch.bfloat16, device=dev())
-    lse_p = torch.zeros(B + 1, heads, S, device=dev())
+    lse_p = torch.zeros(pk.nseq, heads, S, device=dev())
     dqkv_p = torch.full((pk.Mp, 3 * H), float("nan"), dtype=torch.bfloat16, device=dev())
-    hip.attention_fwd(qkv_p, pk.mask, B + 1, S, heads, True, out_p, lse_p, drop=d, cu=pk.cu)
-    hip.attention_bwd(qkv_p, out_p, dout_p, lse_p, pk.mask, B + 1, S, heads, True, dqkv_p, drop=d, cu=pk.cu)
+    hip.attention_fwd(qkv_p, pk.mask, pk.nseq, S, heads, True, out_p, lse_p, drop=d, cu=pk.cu)
+    hip.attention_bwd(qkv_p, out_p, dout_p, lse_p, pk.mask, pk.nseq, S, heads, True, dqkv_p, drop=d, cu=pk.cu)
     assert torch.equal(out_p[:pk.n], out[rows]), "forward rows differ"
     for b, n in enumerate(lens):
         assert torch.equal(lse_p[b, :, :n], lse[b, :, :n])
