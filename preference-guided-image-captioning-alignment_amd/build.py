@@ -42,7 +42,18 @@ def _stale(target: str, deps: List[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, variant: str = "", extra_flags=()) -> str:
+    """``variant`` (diagnostic builds: e.g. "timing" with ``-DPGCA_GEMM_TIMING``) goes to its own object directory and
+    ``libpgca_hip_<variant>.so``; load it with ``PGCA_LIB=<path>`` (pgca_amd.hip).  The product library has no variant."""
+    obj_dir, lib = OBJ, LIB
+    flags = list(FLAGS) + list(extra_flags)
+    if variant:
+        obj_dir = os.path.join(CSRC, "_obj_" + variant)
+        lib = os.path.join(HERE, f"libpgca_hip_{variant}.so")
+    return _build(force, verbose, obj_dir, lib, flags)
+
+
+def _build(force: bool, verbose: bool, OBJ: str, LIB: str, FLAGS) -> str:
     os.makedirs(OBJ, exist_ok=True)
     common = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")] + [HEADER]
     cc = hipcc()
@@ -78,4 +89,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    variant = ""
+    extra = []
+    for a in args:
+        if a.startswith("--variant="):
+            variant = a.split("=", 1)[1]
+        elif a.startswith("-D"):
+            extra.append(a)
+    print(build(force="--force" in sys.argv, variant=variant, extra_flags=extra))

@@ -157,7 +157,10 @@ class NaNSafeGradientNorm:
                 raise RuntimeError("Non-finite gradient norm detected")
             return total, False
         for g in grads:
-            hip.scale_dev(g.view(-1), g.numel(), coef)
+            if g.numel() % 4 == 0 and g.data_ptr() % 16 == 0:
+                hip.scale_dev(g.view(-1), g.numel(), coef)
+            else:                                   # odd-sized tensors: the same device-side factor, no read-back
+                g.mul_(coef[0])
         return total, True
 
     forward = __call__

@@ -83,6 +83,20 @@ __device__ __forceinline__ void wait_vm_p() {
 #else
 #define PSTAMP(v)
 #endif
+// Diagnostic fillers (-DPGCA_FILL_L=n / -DPGCA_FILL_M=n): n independent VALU instructions per L phase (after its copy
+// instructions, before the barrier) / per MFMA gap.  They calibrate how much epilogue work of a PREVIOUS tile the main
+// loop could carry for free (tools/gemm_fill_probe.sh); never defined in the product build.
+#ifndef PGCA_FILL_L
+#define PGCA_FILL_L 0
+#endif
+#ifndef PGCA_FILL_M
+#define PGCA_FILL_M 0
+#endif
+template <int N>
+__device__ __forceinline__ void valu_fill(float (&d)[8]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("v_fmac_f32 %0, %1, %1" : "+v"(d[i & 7]) : "v"(d[(i + 3) & 7]));
+}
 #define PGCA_PBAR()                       \
   do {                                    \
     __builtin_amdgcn_sched_barrier(0);    \
@@ -95,8 +109,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
                                                           int stagger) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smems[];  // [4 stages][A 16 KiB | B 16 KiB]
 #ifdef PGCA_GEMM_TIMING
-  unsigned long long ts0;
+  unsigned long long ts0, tr0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts0)::"memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr0)::"memory");   // constant 100 MHz
 #endif
 
   // De-phasing: with 128 KiB of LDS one workgroup owns a CU, every CU starts its tile at the same time and all 256
@@ -177,6 +192,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
   unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0, q8 = 0;
   unsigned long long aL0 = 0, aB1 = 0, aM0 = 0, aB2 = 0, aL1 = 0, aB3 = 0, aM1 = 0, aB4 = 0;
 #endif
+  float fill[8] = {1.f, 2.f, 3.f, 4.f, 5.f, 6.f, 7.f, 8.f};
   for (int kt = 0; kt < nk; ++kt) {
     PSTAMP(q0);
     const unsigned char* la = smems + (kt & 3) * 2 * PTILE_BYTES;
@@ -190,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
     __builtin_amdgcn_sched_barrier(0);
     if (kt >= 1 && kt + 2 < nk) db.issue(bbase + (size_t)(kt + 2) * bstep, smems + ((kt + 2) & 3) * 2 * PTILE_BYTES + PTILE_BYTES, wave);
     if (kt == 0 && 2 < nk) db.issue(bbase + 2 * bstep, smems + 5 * PTILE_BYTES, wave);
+    if (PGCA_FILL_L) valu_fill<PGCA_FILL_L>(fill);
     PSTAMP(q1);
     PGCA_PBAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // after the barrier: the fragment latency hides in the barrier wait
@@ -200,7 +217,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[0][i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[0][i][j], 0, 0, 0);
+        if (PGCA_FILL_M) valu_fill<PGCA_FILL_M>(fill);
+      }
     __builtin_amdgcn_s_setprio(0);
     PSTAMP(q3);
     PGCA_PBAR();
@@ -217,6 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
     } else {
       wait_vm_p<0>();
     }
+    if (PGCA_FILL_L) valu_fill<PGCA_FILL_L>(fill);
     PSTAMP(q5);
     PGCA_PBAR();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -227,7 +248,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[1][i][j], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[1][i][j], 0, 0, 0);
+        if (PGCA_FILL_M) valu_fill<PGCA_FILL_M>(fill);
+      }
     __builtin_amdgcn_s_setprio(0);
     PSTAMP(q7);
     PGCA_PBAR();
@@ -245,6 +269,9 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
     o[4] = aL1 * inv; o[5] = aB3 * inv; o[6] = aM1 * inv; o[7] = aB4 * inv;
   }
 #endif
+  if (PGCA_FILL_L || PGCA_FILL_M) {  // keep the fillers alive
+    if (fill[0] + fill[1] + fill[2] + fill[3] + fill[4] + fill[5] + fill[6] + fill[7] == 12345.678f) acc[0][0][0][0] += 1.f;
+  }
   if (wm == 0) PGCA_PBAR();  // re-join the groups
   __syncthreads();           // the epilogue stages through the same LDS
 
@@ -259,6 +286,10 @@ __global__ __launch_bounds__(512, 2) void gemm256s_kernel(const pgca_gemm_args a
     float* o = a.stat_max + ((size_t)blockIdx.x * 8 + wave) * 8;
     o[0] = (float)(ts1 - ts0); o[1] = (float)(ts2 - ts1); o[2] = (float)(ts3 - ts2); o[3] = (float)(nk / 2);
     o[4] = (float)(ts0 & 0xFFFFFFFull); o[5] = (float)(ts3 & 0xFFFFFFFull);  // wrap at 2^28 clocks
+    // in-kernel shader clock (MI355X_MICROARCH.md, DVFS item 6): (ts3 - ts0) / (tr3 - tr0) x 100 MHz
+    unsigned long long tr3;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tr3)::"memory");
+    o[6] = (float)(ts3 - ts0); o[7] = (float)(tr3 - tr0);
   }
 #endif
 }

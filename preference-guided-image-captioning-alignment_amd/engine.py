@@ -12,6 +12,7 @@ Reference call sites replaced are cited per method.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -829,7 +830,7 @@ class CaptionDecoderEngine:
 
     # rows of dlogits materialised at a time in the LM-head backward (bf16 workspace, 0.8 GB): 32 x 197 tiles = 24.6 rounds
     # of the 256 CUs (a 4096-row chunk ends on a 31 %-full 13th round)
-    LM_CHUNK = 8192
+    LM_CHUNK = int(os.environ.get("PGCA_LM_CHUNK", "8192"))
 
     def __init__(self, store: ParamStore, arch: ModelArch, ws: Workspace, tag: str):
         self.arch, self.ws, self.tag = arch, ws, tag

@@ -13,7 +13,9 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgca_hip.so")
+# PGCA_LIB: a diagnostic build of the same ABI (python -m pgca_amd.build --variant=timing -DPGCA_GEMM_TIMING); the product
+# library is the in-tree libpgca_hip.so
+LIB_PATH = os.environ.get("PGCA_LIB") or os.path.join(_HERE, "libpgca_hip.so")
 
 NT, NN, TN = 0, 1, 2
 EPI_NONE, EPI_GELU_NEW, EPI_QUICK_GELU, EPI_RELU, EPI_TANH = 0, 1, 2, 3, 4

@@ -211,13 +211,19 @@ def test_packed_dpo_step_equals_padded(S, lens, train, ref_free):
         # the vision head sits behind the per-sequence f32 ATOMIC sums of the embedding backward (dattended / dU: order not
         # reproducible from launch to launch in either layout) followed by a bf16 GEMM chain, so its gradient carries
         # bf16 rounding noise between any two runs; the decoder's own gradients only differ by f32 summation order
-        cmin, rel = (0.9999, 3e-2) if name == "vision_head" else (0.999999, 2e-3)
+        # (the same holds for the decoder's own cross-attention / vision_projection / attention_norm tensors, which sit
+        # behind those atomics too; the GPT-2 trunk, ln_f, wte and wpe do not)
+        cmin = 0.9999 if name == "vision_head" else 0.99999
         assert _cos(g0[name], g1[name]) >= cmin, name
         for key in list(seg.index)[:400]:
             off, n = seg.index[key][0], int(np.prod(seg.index[key][1]))
             a, b = g0[name][off:off + n], g1[name][off:off + n]
             scale = float(a.abs().max())
+            trunk = ".transformer." in key
+            rel = 2e-3 if trunk else 3e-2
             assert float((a - b).abs().max()) <= rel * scale + 1e-9, f"{key}: {float((a - b).abs().max())} vs {scale}"
+            if trunk and scale > 0:
+                assert _cos(a, b) >= 0.999999, key
 
 
 @pytest.mark.parametrize("train", [False, True])

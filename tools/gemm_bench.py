@@ -115,6 +115,11 @@ def main():
                 print(f"   per-workgroup clocks: prologue {m[0]:.0f} main loop {m[1]:.0f} "
                       f"({m[1] / max(float(m[3]), 1):.0f}/K-tile) epilogue {m[2]:.0f}")
                 w0 = tb.view(-1, 8, 8)[:, 0]          # wave 0 of every workgroup (last launch)
+                ok = w0[:, 7] > 0
+                if bool(ok.any()):     # in-kernel shader clock: d s_memtime / d s_memrealtime x 100 MHz, median over workgroups
+                    ghz = (w0[ok, 6].double() / w0[ok, 7].double() * 0.1).median()
+                    print(f"   in-kernel clock (s_memtime / s_memrealtime x 100 MHz, median of {int(ok.sum())} workgroups): "
+                          f"{float(ghz):.3f} GHz")
                 st, en = w0[:, 4].double(), w0[:, 5].double()
                 if float(en.max()) > 0:
                     t0 = float(st.min())
