@@ -46,6 +46,7 @@ def main():
     for a in ("sq", "fetch", "write", "tcc"):
         ap.add_argument("--" + a, required=True)
     ap.add_argument("--pairs", type=int, default=128)
+    ap.add_argument("--commit", default="")
     ap.add_argument("--out", required=True)
     ap.add_argument("--top", type=int, default=14)
     a = ap.parse_args()
@@ -75,7 +76,7 @@ def main():
                 row["l2_hit_rate"] = h / (h + m)
         rows.append(row)
     out = {"command": "rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-probe "
-                      "(one pass per counter set)", "pairs_per_gpu": a.pairs, "note": __doc__.split("\n\n")[1], "kernels": rows}
+                      "(one pass per counter set)", "pairs_per_gpu": a.pairs, "commit": a.commit, "note": __doc__.split("\n\n")[1], "kernels": rows}
     with open(a.out, "w") as fh:
         json.dump(out, fh, indent=1)
     for r in rows:
