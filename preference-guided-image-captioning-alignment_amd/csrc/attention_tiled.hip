@@ -41,6 +41,27 @@ __device__ __forceinline__ void stage_rows(unsigned char* lds, const bf16_t* g, 
   }
 }
 
+// the same in two halves, so that the global loads of several tiles can be in flight together before any of them is waited for
+struct StageRegs {
+  u32x4 v[1024 / TNT];
+};
+__device__ __forceinline__ void stage_load(StageRegs& r, const bf16_t* g, int ld, int row0, int S, int t) {
+#pragma unroll
+  for (int i = 0; i < 1024 / TNT; ++i) {
+    const int idx = t + TNT * i;
+    const int row = idx >> 3, c = idx & 7;
+    r.v[i] = (u32x4){0u, 0u, 0u, 0u};
+    if (row0 + row < S) r.v[i] = *reinterpret_cast<const u32x4*>(g + (size_t)(row0 + row) * ld + c * 8);
+  }
+}
+__device__ __forceinline__ void stage_store(const StageRegs& r, unsigned char* lds, int t) {
+#pragma unroll
+  for (int i = 0; i < 1024 / TNT; ++i) {
+    const int idx = t + TNT * i;
+    *reinterpret_cast<u32x4*>(lds + (idx >> 3) * QS + (idx & 7) * 16) = r.v[i];
+  }
+}
+
 // MFMA operand whose 16 rows (A) / 16 columns (B) are image rows row0..row0+15 and whose k is contiguous (64-deep image)
 __device__ __forceinline__ bf16x8 frag_rows64(const unsigned char* lds, int row0, int kk, int lane) {
   return *reinterpret_cast<const bf16x8*>(lds + (row0 + (lane & 15)) * QS + kk * 64 + (lane >> 4) * 16);
@@ -249,6 +270,15 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
   const bf16_t* dobase = dO + (size_t)row0 * H + h * DH;
   bf16_t* dbase_g = dqkv + (size_t)row0 * ld + h * DH;
 
+  // One workgroup per CU (108 KiB of LDS) means nobody hides this workgroup's memory latency: the first (key block,
+  // query block) pair's four tiles are REQUESTED here, together with the row constants below, and stored to LDS after
+  // them - one HBM round trip in front of the first MFMA instead of three (row constants, K/V, Q/dO).  With packed
+  // sequences (mean length 72 of 128) most workgroups have exactly one pair.
+  StageRegs pk, pv, pq, pdo;
+  stage_load(pk, base + H, ld, 0, S, t);
+  stage_load(pv, base + 2 * H, ld, 0, S, t);
+  stage_load(pq, base, ld, 0, S, t);
+  stage_load(pdo, dobase, H, 0, S, t);
   // row constants of every query: lse and delta[q] = sum_d dO[q,d] O[q,d] (8 lanes per row)
   for (int idx = t; idx < NQB * TB * 8; idx += TNT) {
     const int row = idx >> 3, c = idx & 7;
@@ -279,8 +309,15 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
   for (int kb = 0; kb < nblk; ++kb) {
     const int k0 = kb * TB;
     // (the barrier that closes the previous pair protects Ks / Vs / kms)
-    stage_rows(Ks, base + H, ld, k0, S, t);
-    stage_rows(Vs, base + 2 * H, ld, k0, S, t);
+    if (kb == 0) {   // requested at the top; the first query block (0 in both mask modes) comes with them
+      stage_store(pk, Ks, t);
+      stage_store(pv, Vs, t);
+      stage_store(pq, Qs, t);
+      stage_store(pdo, dOs, t);
+    } else {
+      stage_rows(Ks, base + H, ld, k0, S, t);
+      stage_rows(Vs, base + 2 * H, ld, k0, S, t);
+    }
     if (t < TB) kms[t] = (k0 + t < S && (!kmask || kmask[b * Sp + k0 + t] != 0)) ? 1 : 0;
     __syncthreads();
     const int keyw = k0 + 16 * w;            // this wave's first key
@@ -302,9 +339,11 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
     for (int qb = causal ? kb : 0; qb < nblk; ++qb) {
       {
         const int q0 = qb * TB;
-        stage_rows(Qs, base, ld, q0, S, t);
-        stage_rows(dOs, dobase, H, q0, S, t);
-        __syncthreads();
+        if (kb != 0 || qb != 0) {   // (pair (0, 0) was staged with the key block)
+          stage_rows(Qs, base, ld, q0, S, t);
+          stage_rows(dOs, dobase, H, q0, S, t);
+          __syncthreads();
+        }
         // ---- phase A: S, dP (key on the lane) -> P, dS -> dV^t, dK^t; dS^t to LDS
         const int nqt = min(8, (S - q0 + 15) >> 4);          // 16-query tiles with a real row
         // on the diagonal block queries below this wave's first key see none of its keys
