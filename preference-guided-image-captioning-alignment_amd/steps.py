@@ -161,7 +161,7 @@ class DPOStep:
         emb2[:B].copy_(emb)
         emb2[B:].copy_(emb)
         ref_lp = None
-        packed = self.packed and sb.pack is not None
+        packed = self.packed and sb.pack is not None and sb.pack.Mp > 0
         if not self.reference_free:
             # the frozen reference policy runs on its own HIP stream, concurrently with the policy forward:
             # the two kernel sequences are independent, so one's store-bound epilogues and tile tails are
@@ -235,7 +235,8 @@ class ContrastiveStep:
     def _pack(self, mask, pack: Optional[RowPack]) -> Optional[RowPack]:
         if not self.packed:
             return None
-        return pack if pack is not None else make_row_pack(mask.contiguous())   # (one host wait; prepare() avoids it)
+        pack = pack if pack is not None else make_row_pack(mask.contiguous())   # (one host wait; prepare() avoids it)
+        return pack if pack.Mp > 0 else None     # a batch of empty captions: nothing to pack, the padded path handles it
 
     def forward(self, images, ids, mask, save: bool = True, pack: Optional[RowPack] = None):
         """``pack`` (``prepare()['pack']``): packed row layout of ``mask``; the text tower then computes the real tokens
