@@ -116,6 +116,106 @@ class GpuImageProcessor:
         return out
 
 
+class TokenisedCaptionCache:
+    """Tokenised-caption cache (reference ``TextProcessor.encode_caption``, data/preprocessing.py:206-238,
+    called once per sample per epoch from ``ConceptualCaptionsDataset.__getitem__`` / ``UltraFeedbackDataset.__getitem__``,
+    data/loader.py:239-258,470-497).  The reference re-runs the tokenizer for the same caption every epoch; here every distinct
+    caption is encoded ONCE into a row of a pinned ``[capacity, max_length]`` int64 table (ids) and its int64 mask table, and
+    batches are gathered by row index - a memcpy into staging that the H2D copy engine can take directly.
+
+    ``tokenizer``: anything callable the way the reference calls HF's (``tokenizer(caption, max_length=, padding=,
+    truncation=, add_special_tokens=, return_tensors="pt", return_attention_mask=)`` -> mapping with ``input_ids`` /
+    ``attention_mask`` of shape [1, L]).  ``encode_caption`` returns exactly what the reference's method returns
+    (``{"input_ids": [max_length], "attention_mask": [max_length]}`` for ``padding="max_length"``); rows shorter than
+    ``max_length`` (a ``padding="longest"`` tokenizer) are right-padded with ``pad_token_id`` and mask 0, the layout the step
+    kernels' packed rows assume.  ``save`` / ``load`` persist the table (captions hashed, not stored)."""
+
+    def __init__(self, tokenizer, max_length: int = 128, padding: str = "max_length", truncation: bool = True,
+                 capacity: int = 1024, pin: bool = True):
+        self.tokenizer, self.max_length, self.padding, self.truncation = tokenizer, int(max_length), padding, truncation
+        self._pin = bool(pin) and torch.cuda.is_available()
+        self._rows = {}
+        self._n = 0
+        self._alloc(max(1, int(capacity)))
+        self.hits = self.misses = 0
+
+    def _alloc(self, cap: int) -> None:
+        ids = torch.zeros(cap, self.max_length, dtype=torch.int64)
+        mask = torch.zeros(cap, self.max_length, dtype=torch.int64)
+        if self._pin:
+            ids, mask = ids.pin_memory(), mask.pin_memory()
+        if self._n:
+            ids[:self._n].copy_(self.ids[:self._n])
+            mask[:self._n].copy_(self.mask[:self._n])
+        self.ids, self.mask = ids, mask
+
+    @staticmethod
+    def _key(caption: str, add_special_tokens: bool) -> str:
+        import hashlib
+        return hashlib.sha1((("1" if add_special_tokens else "0") + caption).encode("utf-8")).hexdigest()
+
+    def row_of(self, caption: str, add_special_tokens: bool = True) -> int:
+        key = self._key(caption, add_special_tokens)
+        r = self._rows.get(key)
+        if r is not None:
+            self.hits += 1
+            return r
+        self.misses += 1
+        try:
+            enc = self.tokenizer(caption, max_length=self.max_length, padding=self.padding, truncation=self.truncation,
+                                 add_special_tokens=add_special_tokens, return_tensors="pt", return_attention_mask=True)
+        except Exception as e:  # reference preprocessing.py:236-238
+            raise ValueError(f"Failed to encode caption: {e}") from e
+        ids = torch.as_tensor(enc["input_ids"]).reshape(-1).to(torch.int64)
+        am = enc.get("attention_mask") if hasattr(enc, "get") else None
+        am = torch.ones_like(ids) if am is None else torch.as_tensor(am).reshape(-1).to(torch.int64)
+        if ids.numel() > self.max_length:
+            raise ValueError(f"Failed to encode caption: {ids.numel()} tokens exceed max_length={self.max_length} "
+                             "(truncation is off)")
+        if self._n == self.ids.shape[0]:
+            self._alloc(2 * self._n)
+        r = self._n
+        n = ids.numel()
+        pad = getattr(self.tokenizer, "pad_token_id", None)
+        self.ids[r].fill_(0 if pad is None else int(pad))
+        self.ids[r, :n] = ids
+        self.mask[r, :n] = am
+        self._rows[key] = r
+        self._n += 1
+        return r
+
+    def encode_caption(self, caption: str, add_special_tokens: bool = True, return_attention_mask: bool = True):
+        r = self.row_of(caption, add_special_tokens)
+        return {"input_ids": self.ids[r].clone(), "attention_mask": self.mask[r].clone()}
+
+    def encode_batch(self, captions, add_special_tokens: bool = True):
+        """[B, max_length] ids and masks of a list of captions: one gather from the table."""
+        rows = torch.as_tensor([self.row_of(c, add_special_tokens) for c in captions], dtype=torch.int64)
+        return {"input_ids": self.ids.index_select(0, rows), "attention_mask": self.mask.index_select(0, rows)}
+
+    def __len__(self) -> int:
+        return self._n
+
+    def save(self, path: str) -> None:
+        import numpy as np
+        keys = sorted(self._rows, key=self._rows.get)
+        np.savez_compressed(path, ids=self.ids[:self._n].numpy(), mask=self.mask[:self._n].numpy(),
+                            keys=np.array(keys), max_length=np.int64(self.max_length))
+
+    def load(self, path: str) -> None:
+        import numpy as np
+        z = np.load(path, allow_pickle=False)
+        if int(z["max_length"]) != self.max_length:
+            raise ValueError(f"cache was built for max_length={int(z['max_length'])}, not {self.max_length}")
+        n = z["ids"].shape[0]
+        self._n = 0
+        self._alloc(max(n, 1))
+        self.ids[:n].copy_(torch.from_numpy(z["ids"]))
+        self.mask[:n].copy_(torch.from_numpy(z["mask"]))
+        self._rows = {str(k): i for i, k in enumerate(z["keys"])}
+        self._n = n
+
+
 def _pin(x):
     if isinstance(x, torch.Tensor) and not x.is_cuda and not x.is_pinned():
         return x.pin_memory()

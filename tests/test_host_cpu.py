@@ -96,3 +96,43 @@ def test_product_never_imports_the_oracle():
         if f.endswith(".py"):
             src = open(os.path.join(pkg, f)).read()
             assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_tokenised_caption_cache_against_a_real_hf_tokenizer(tmp_path):
+    """N2: the tokenised-caption cache returns what the reference's ``TextProcessor.encode_caption``
+    (data/preprocessing.py:206-238) returns - the HF tokenizer called with the reference's arguments - for a tokenizer
+    built locally (no hub files: WordLevel vocab + the reference's added [PAD]/[BOS]/[EOS] special tokens), encodes every
+    distinct caption once, and survives a save / load."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+
+    from pgca_amd.input import TokenisedCaptionCache
+    words = "a cat dog sits on the mat red blue big small runs fast [UNK]".split()
+    tk = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    hf = PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="[UNK]")
+    hf.add_special_tokens({"pad_token": "[PAD]", "bos_token": "[BOS]", "eos_token": "[EOS]"})   # preprocessing.py:185-199
+    S = 8
+    cache = TokenisedCaptionCache(hf, max_length=S, capacity=2, pin=False)
+    caps = ["a cat sits on the mat", "the big red dog runs fast on the small blue mat", "a zebra", "a cat sits on the mat"]
+    for c in caps:
+        want = hf(c, max_length=S, padding="max_length", truncation=True, add_special_tokens=True, return_tensors="pt",
+                  return_attention_mask=True)
+        got = cache.encode_caption(c)
+        assert torch.equal(got["input_ids"], want["input_ids"].squeeze(0))
+        assert torch.equal(got["attention_mask"], want["attention_mask"].squeeze(0))
+        assert got["input_ids"].shape == (S,) and got["input_ids"].dtype == torch.int64
+    assert len(cache) == 3 and cache.misses == 3 and cache.hits == 1          # the repeated caption was not re-tokenised
+    b = cache.encode_batch(caps)
+    assert b["input_ids"].shape == (4, S) and torch.equal(b["input_ids"][0], b["input_ids"][3])
+    assert int(b["attention_mask"][1].sum()) == S                              # truncated to max_length
+    # right padding with the pad id and mask 0: the layout the packed rows rely on
+    assert bool((b["input_ids"][2][b["attention_mask"][2] == 0] == hf.pad_token_id).all())
+    path = str(tmp_path / "captions.npz")
+    cache.save(path)
+    fresh = TokenisedCaptionCache(lambda *a, **k: (_ for _ in ()).throw(AssertionError("tokenizer called")), max_length=S,
+                                  pin=False)
+    fresh.load(path)
+    assert torch.equal(fresh.encode_batch(caps)["input_ids"], b["input_ids"]) and fresh.misses == 0
+    with pytest.raises(ValueError, match="Failed to encode caption"):
+        fresh.encode_caption("never seen")
