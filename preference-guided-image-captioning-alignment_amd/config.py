@@ -23,6 +23,7 @@ MI355X_DEFAULTS = {
     "gpt2_pdrop": 0.1,                                          # HF GPT2Config embd/attn/resid dropout (train mode)
     "allreduce_bf16": False,                                    # bf16-compressed gradient all-reduce (halves xGMI bytes)
     "reset_best_val_between_stages": False,                     # False = as the reference: Stage 2 inherits best_val_loss
+    "packed_rows": True,                                        # trunks run on the real tokens' rows only (same results)
 }
 
 

@@ -180,7 +180,7 @@ class PreferenceGuidedTrainer:
         step = ContrastiveStep(m.store, m.ws, m.vision_encoder.tower, m.vision_encoder.head, m.text_encoder.engine,
                                self.temperature, dp=self.dp,
                                global_negatives=bool(self.config.get("mi355x.stage1.global_negatives", False)),
-                               dropout=self._dropout_plan(1))
+                               dropout=self._dropout_plan(1), packed=bool(self.config.get("mi355x.packed_rows", True)))
         reducer = OverlappedTrunkReducer(self.dp, m.text_encoder.engine.trunk,
                                          group=int(self.config.get("mi355x.allreduce_layer_group", 4)))
         extra = [s for s in opt.segments if s is not reducer.seg]
@@ -209,7 +209,7 @@ class PreferenceGuidedTrainer:
         step = DPOStep(m.store, m.ws, m.vision_encoder.tower, m.vision_encoder.head, m.caption_decoder.engine,
                        beta=self.beta, reference_free=reference_free,
                        label_smoothing=float(self.config.get("mi355x.dpo.label_smoothing", 0.0)), ref=ref,
-                       dropout=self._dropout_plan(2))
+                       dropout=self._dropout_plan(2), packed=bool(self.config.get("mi355x.packed_rows", True)))
         reducer = OverlappedTrunkReducer(self.dp, m.caption_decoder.engine.trunk,
                                          group=int(self.config.get("mi355x.allreduce_layer_group", 4)))
         extra = [s for s in opt.segments if s is not reducer.seg]
