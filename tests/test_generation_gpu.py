@@ -213,3 +213,34 @@ def test_skinny_gemm_against_fp32(M, N, K, act, fuse_ln):
     if fuse_ln:
         want = torch.nn.functional.layer_norm(out_f, (N,), gamma, beta, 1e-5)
         assert float((ln_out.float() - want).abs().max()) <= 2 ** -7 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("R", [1, 5, 40])
+def test_decode_step_at_real_width(R):
+    """GPT-2-M width (H = 1024, 16 heads, 2 layers): the K/V-cache decode - skinny products with the LayerNorms fused into
+    their finish passes for R <= 32 rows, tile GEMMs above - against the cache-free recomputation at every position, and
+    against the oracle at the last one."""
+    from pgca_amd.arch import make_arch, with_layers
+    from pgca_amd.model import PreferenceGuidedCaptioningModel
+    arch = with_layers(make_arch("openai/clip-vit-base-patch32", "gpt2-medium", 512), 1, 2)
+    m = PreferenceGuidedCaptioningModel(freeze_vision_backbone=True, arch=arch, seed=23, device=DEV)
+    eng = m.caption_decoder.engine
+    gen = torch.Generator().manual_seed(R)
+    emb = torch.randn(R, 512, generator=gen)
+    toks = torch.randint(0, 50257, (R, 5), generator=gen)
+    pv = eng.prefix_embedding(emb.to(DEV))
+    worst = 0.0
+    for graphs in (False, True, True):
+        eng.use_graphs = graphs
+        lc = eng.decode_begin(pv, 6).clone()
+        for t in range(6):
+            lf = eng.next_token_logits(pv, toks[:, :t].to(DEV))
+            worst = max(worst, float((lc - lf).abs().max()))
+            if t < 5:
+                lc = eng.decode_advance(toks[:, t].to(DEV)).clone()
+    sd = {k: v.detach().cpu() for k, v in m.store.state_dict(aliases=False).items()}
+    if R <= 5:
+        from oracle import restatement as Rm
+        ref = Rm.generate_step_logits(sd, emb, toks, arch.gpt.heads)
+        assert float((lc.cpu() - ref).abs().max()) <= 5e-2
+    assert worst <= 3e-2, worst
