@@ -162,10 +162,11 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-300))
 
 
-@pytest.mark.parametrize("S,lens,train,ref_free", [
-    (128, [128, 40, 77, 16], False, True), (128, [100, 33, 64, 128], True, False),
-    (256, [256, 130, 77, 200], True, True), (256, [17, 250, 129, 128], False, False)])
-def test_packed_dpo_step_equals_padded(S, lens, train, ref_free):
+@pytest.mark.parametrize("S,lens,train,ref_free,holes", [
+    (128, [128, 40, 77, 16], False, True, ()), (128, [100, 33, 64, 128], True, False, ()),
+    (256, [256, 130, 77, 200], True, True, ()), (256, [17, 250, 129, 128], False, False, ()),
+    (128, [90, 128, 5, 61], True, False, ((0, 7), (0, 8), (1, 100), (3, 1)))])   # masks with holes inside a caption
+def test_packed_dpo_step_equals_padded(S, lens, train, ref_free, holes):
     """Stage-2 step (2-forward and 4-forward), eval and train mode (dropout 0.1 at every site): scored log-probs of the
     policy and of the reference policy, loss, and every gradient tensor - packed rows vs all B*S rows."""
     from pgca_amd.engine import DropoutPlan
@@ -175,7 +176,7 @@ def test_packed_dpo_step_equals_padded(S, lens, train, ref_free):
     B = 2
     img = torch.randn(B, 3, 224, 224, generator=gen)
     ids = torch.randint(0, 50257, (2 * B, S), generator=gen)
-    mask = ragged_mask(2 * B, S, lens)
+    mask = ragged_mask(2 * B, S, lens, holes)
     ids = torch.where(mask.bool(), ids, torch.full_like(ids, 50257))
     batch = {"image": img, "preferred_ids": ids[:B], "rejected_ids": ids[B:], "preferred_mask": mask[:B],
              "rejected_mask": mask[B:]}
