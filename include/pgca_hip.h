@@ -36,7 +36,7 @@ typedef enum pgca_status {
   PGCA_ERR_LAUNCH = -2   /* hipLaunch failed; see pgca_last_error() */
 } pgca_status;
 
-#define PGCA_ABI_VERSION 302 /* bumped whenever a signature or struct layout below changes */
+#define PGCA_ABI_VERSION 303 /* bumped whenever a signature or struct layout below changes */
 int pgca_version(void);        /* == PGCA_ABI_VERSION of the header the library was built from */
 int pgca_sizeof_gemm_args(void); /* sizeof(pgca_gemm_args) as compiled: bindings compare it with their own layout */
 const char* pgca_last_error(void);
@@ -64,7 +64,12 @@ enum {
                               + target-logit pick; fused LM head / NT-Xent (model.py:1069-1079,988-998) */
   PGCA_EPI_DLOGITS = 9,    /* v = row_scale[m] * (exp(v - row_lse[m]) - (n == target[m])); 0 for n >= N;
                               aux_out (opt., bf16 [M, ld_aux]) <- bf16(v - bf16(v)): low half of a hi/lo split */
-  PGCA_EPI_DQUICK_GELU = 10 /* v *= quick_gelu'(aux_in[m,n]) (aux_in = saved pre-activation; trainable CLIP tower) */
+  PGCA_EPI_DQUICK_GELU = 10, /* v *= quick_gelu'(aux_in[m,n]) (aux_in = saved pre-activation; trainable CLIP tower) */
+  /* The GPT-2 MLP pair that evaluates the sigmoid ONCE: the forward epilogue has it in registers for gelu_new and writes
+   * gelu_new'(pre) beside the activation; the backward epilogue is then a plain multiply instead of exp + rcp + 8 FMAs
+   * per element on the K = 1024 data-gradient GEMM whose epilogue was 40 % of its tile life. */
+  PGCA_EPI_GELU_NEW_D = 11,  /* like GELU_NEW, but aux_out <- gelu_new'(pre-activation) (bf16) */
+  PGCA_EPI_MUL_AUX = 12      /* v *= aux_in[m,n] (aux_in = the derivative saved by GELU_NEW_D); colsum_part allowed */
 };
 
 typedef struct pgca_gemm_args {
@@ -102,7 +107,7 @@ typedef struct pgca_gemm_args {
   uint32_t drop_seed;
   uint32_t drop_threshold;
   float drop_scale;
-  /* Optional, PGCA_EPI_DGELU_NEW only: f32 [ceil(M/64), ld_colsum] - row b receives the column sums of the rows
+  /* Optional, PGCA_EPI_DGELU_NEW / PGCA_EPI_MUL_AUX only: f32 [ceil(M/64), ld_colsum] - row b receives the column sums of the rows
    * 64b .. 64b+63 of the result (before its bf16 rounding); summed over b (pgca_colsum_finish) they are the bias gradient
    * of the layer whose pre-activation gradient this GEMM produces, without a second pass over the M x N result. */
   float* colsum_part;

@@ -58,6 +58,14 @@ __device__ __forceinline__ float dgelu_new(float x) {
   const float s = fast_sigmoid(k2 * x * (1.0f + 0.044715f * x2));
   return s + x * s * (1.0f - s) * k2 * (1.0f + 3.0f * 0.044715f * x2);
 }
+// both from one sigmoid (forward epilogue PGCA_EPI_GELU_NEW_D)
+__device__ __forceinline__ void gelu_new_both(float x, float& y, float& dy) {
+  const float k2 = 2.0f * 0.7978845608028654f;
+  const float x2 = x * x;
+  const float s = fast_sigmoid(k2 * x * (1.0f + 0.044715f * x2));
+  y = x * s;
+  dy = s + y * (1.0f - s) * k2 * (1.0f + 3.0f * 0.044715f * x2);
+}
 // HF QuickGELUActivation (transformers/activations.py:117-123)
 __device__ __forceinline__ float quick_gelu(float x) { return x * fast_sigmoid(1.702f * x); }
 __device__ __forceinline__ float dquick_gelu(float x) {

@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const pgca_gemm_args a, in
     case PGCA_EPI_DTANH: epilogue_store<PGCA_EPI_DTANH>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
     case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
     case PGCA_EPI_DQUICK_GELU: epilogue_store<PGCA_EPI_DQUICK_GELU>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_GELU_NEW_D: epilogue_store<PGCA_EPI_GELU_NEW_D>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
+    case PGCA_EPI_MUL_AUX: epilogue_store<PGCA_EPI_MUL_AUX>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
     default: epilogue_store<PGCA_EPI_NONE>(a, acc, sbase, m0, n0, wm, wn, lane, wave); break;
   }
 }
@@ -461,14 +463,16 @@ extern "C" int pgca_gemm_bf16(const pgca_gemm_args* args, void* stream) {
       set_error("pgca_gemm_bf16: no output buffer");
       return PGCA_ERR_INVALID;
     }
-    if (((a.epilogue >= PGCA_EPI_DGELU_NEW && a.epilogue <= PGCA_EPI_DTANH) || a.epilogue == PGCA_EPI_DQUICK_GELU) &&
+    if (((a.epilogue >= PGCA_EPI_DGELU_NEW && a.epilogue <= PGCA_EPI_DTANH) || a.epilogue == PGCA_EPI_DQUICK_GELU ||
+         a.epilogue == PGCA_EPI_MUL_AUX) &&
         !a.aux_in) {
       set_error("pgca_gemm_bf16: derivative epilogue needs aux_in");
       return PGCA_ERR_INVALID;
     }
   }
-  if (a.colsum_part && (a.epilogue != PGCA_EPI_DGELU_NEW || a.ld_colsum < a.N || a.accumulate == 2)) {
-    set_error("pgca_gemm_bf16: colsum_part needs the DGELU_NEW epilogue, ld_colsum >= N and no split-K");
+  if (a.colsum_part && ((a.epilogue != PGCA_EPI_DGELU_NEW && a.epilogue != PGCA_EPI_MUL_AUX) || a.ld_colsum < a.N ||
+                        a.accumulate == 2)) {
+    set_error("pgca_gemm_bf16: colsum_part needs the DGELU_NEW / MUL_AUX epilogue, ld_colsum >= N and no split-K");
     return PGCA_ERR_INVALID;
   }
   const int ncols = a.epilogue == PGCA_EPI_DLOGITS ? a.out_cols : a.N;

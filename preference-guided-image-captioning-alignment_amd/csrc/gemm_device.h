@@ -208,7 +208,16 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
       for (int j = 0; j < 8; ++j) if (j < nv && col + j < a.N) v[j] += bp[j];
     }
   }
-  if (EPI == PGCA_EPI_GELU_NEW || EPI == PGCA_EPI_QUICK_GELU) {
+  if (EPI == PGCA_EPI_GELU_NEW_D) {
+    float dy[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gelu_new_both(v[j], v[j], dy[j]);
+    if (a.aux_out) {
+      bf16_t* p = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(dy[j]);
+    }
+  } else if (EPI == PGCA_EPI_GELU_NEW || EPI == PGCA_EPI_QUICK_GELU) {
     if (a.aux_out) {
       bf16_t* p = reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col;
       if (full && al16(p)) {
@@ -234,7 +243,8 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
 #pragma unroll
       for (int j = 0; j < 8; ++j) if (j < nv) p[j] = f2bf(v[j]);
     }
-  } else if (EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH || EPI == PGCA_EPI_DQUICK_GELU) {
+  } else if (EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH || EPI == PGCA_EPI_DQUICK_GELU ||
+             EPI == PGCA_EPI_MUL_AUX) {
     const bf16_t* p = reinterpret_cast<const bf16_t*>(a.aux_in) + (size_t)row * a.ld_aux + col;
     float x[8];
     if (full && al16(p)) {
@@ -248,6 +258,7 @@ __device__ __forceinline__ void finish8(const pgca_gemm_args& a, int row, int co
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (EPI == PGCA_EPI_DGELU_NEW) v[j] *= dgelu_new(x[j]);
+      else if (EPI == PGCA_EPI_MUL_AUX) v[j] *= x[j];
       else if (EPI == PGCA_EPI_DQUICK_GELU) v[j] *= dquick_gelu(x[j]);
       else if (EPI == PGCA_EPI_DRELU) v[j] = x[j] > 0.f ? v[j] : 0.f;
       else v[j] *= 1.f - x[j] * x[j];
@@ -348,7 +359,7 @@ template <int EPI, int PF>
 __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32x4 (&acc)[4][4], unsigned char* smem,
                                                     int mb, int cb, int lane, int wave) {
   constexpr bool AUXIN = EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_DRELU || EPI == PGCA_EPI_DTANH ||
-                         EPI == PGCA_EPI_DQUICK_GELU;
+                         EPI == PGCA_EPI_DQUICK_GELU || EPI == PGCA_EPI_MUL_AUX;
   float* cbuf = reinterpret_cast<float*>(smem) + wave * CB_WAVE_FLOATS;
   const int r8 = lane >> 3, cg = (lane & 7) * 8;
   const int col = cb + cg;
@@ -357,7 +368,7 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
     b0 = *reinterpret_cast<const float4*>(a.bias + col);
     b1 = *reinterpret_cast<const float4*>(a.bias + col + 4);
   }
-  constexpr bool CSUM = EPI == PGCA_EPI_DGELU_NEW;
+  constexpr bool CSUM = EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_MUL_AUX;
   float cs[8];
   if constexpr (CSUM) {
 #pragma unroll
@@ -404,7 +415,17 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] *= a.alpha;
       v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      if (EPI == PGCA_EPI_GELU_NEW || EPI == PGCA_EPI_QUICK_GELU) {
+      if (EPI == PGCA_EPI_GELU_NEW_D) {
+        bf16x8 tq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float dy;
+          gelu_new_both(v[j], v[j], dy);
+          tq[j] = f2bf(dy);
+        }
+        if (a.aux_out)
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(a.aux_out) + (size_t)row * a.ld_aux + col) = tq;
+      } else if (EPI == PGCA_EPI_GELU_NEW || EPI == PGCA_EPI_QUICK_GELU) {
         if (a.aux_out) {
           bf16x8 tq;
 #pragma unroll
@@ -430,6 +451,7 @@ __device__ __forceinline__ void epilogue_store_fast(const pgca_gemm_args& a, f32
         for (int j = 0; j < 8; ++j) {
           const float x = bf2f(ax[AUXIN ? i8 : 0][j]);
           if (EPI == PGCA_EPI_DGELU_NEW) v[j] *= dgelu_new(x);
+          else if (EPI == PGCA_EPI_MUL_AUX) v[j] *= x;
           else if (EPI == PGCA_EPI_DQUICK_GELU) v[j] *= dquick_gelu(x);
           else if (EPI == PGCA_EPI_DRELU) v[j] = x > 0.f ? v[j] : 0.f;
           else v[j] *= 1.f - x * x;
@@ -519,7 +541,7 @@ __device__ __forceinline__ void epilogue_store(const pgca_gemm_args& a, f32x4 (&
   }
   float* cbuf = reinterpret_cast<float*>(smem) + wave * CB_WAVE_FLOATS;
   const int ncols = EPI == PGCA_EPI_DLOGITS ? a.out_cols : a.N;
-  constexpr bool CSUM = EPI == PGCA_EPI_DGELU_NEW;
+  constexpr bool CSUM = EPI == PGCA_EPI_DGELU_NEW || EPI == PGCA_EPI_MUL_AUX;
   float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
@@ -580,6 +602,8 @@ __device__ __forceinline__ void run_epilogue(const pgca_gemm_args& a, f32x4 (&ac
     case PGCA_EPI_DTANH: epilogue_store<PGCA_EPI_DTANH>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     case PGCA_EPI_DLOGITS: epilogue_store<PGCA_EPI_DLOGITS>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     case PGCA_EPI_DQUICK_GELU: epilogue_store<PGCA_EPI_DQUICK_GELU>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_GELU_NEW_D: epilogue_store<PGCA_EPI_GELU_NEW_D>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
+    case PGCA_EPI_MUL_AUX: epilogue_store<PGCA_EPI_MUL_AUX>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
     default: epilogue_store<PGCA_EPI_NONE>(a, acc, smem, mh, n0, 0, wn, lane, wave); break;
   }
 }

@@ -368,9 +368,11 @@ class GptTrunk:
             r2 = self._buf(k + "r2", (M,), F32)
             hip.layernorm_fwd(hm, M, H, P["ln2w"].w, P["ln2b"].w, a.eps, y_bf16=ln2, mean=m2, rstd=r2)
             act = self._buf(k + "act", (M, I), BF16)
+            # training: the epilogue has the sigmoid of gelu_new in registers and leaves gelu_new'(pre) for the backward, whose
+            # data-gradient GEMM then only multiplies (EPI_MUL_AUX) instead of evaluating the sigmoid a second time
             pre = self._buf(k + "pre", (M, I), BF16) if save else None
-            hip.gemm(ln2, P["wfc"].b, M, I, H, hip.NN, epilogue=hip.EPI_GELU_NEW, bias=P["bfc"].w, out_bf16=act,
-                     aux_out=pre)
+            hip.gemm(ln2, P["wfc"].b, M, I, H, hip.NN, epilogue=hip.EPI_GELU_NEW_D if save else hip.EPI_GELU_NEW,
+                     bias=P["bfc"].w, out_bf16=act, aux_out=pre)
             hn = self._buf(f"l{li + 1}.hin", (M, H), F32) if save else hm
             hip.gemm(act, P["wpr"].b, M, H, I, hip.NN, bias=P["bpr"].w, residual=hm, out_f32=hn,
                      drop=dsite(li, KIND_RESID_MLP), drop_rows=rows)
@@ -513,8 +515,8 @@ class GptTrunk:
             # pass over the M x 4H matrix
             nbr = (M + 63) // 64
             dpre_cs = self._buf("dpre_colsum", (nbr, I), F32)
-            hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=s["pre"], out_bf16=dpre,
-                     colsum_part=dpre_cs)
+            hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_MUL_AUX, aux_in=s["pre"], out_bf16=dpre,
+                     colsum_part=dpre_cs)      # s["pre"] holds gelu_new'(pre-activation) (forward: EPI_GELU_NEW_D)
             hip.colsum_finish(dpre_cs, nbr, I, P["bfc"].g, accumulate=True)
             wgrads = [(s["act"], g_bf, I, H, M, P["wpr"].g)]   # the layer's four weight gradients go out together
             dln = self._buf("dln", (M, H), BF16)

@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("PGCA_LIB") or os.path.join(_HERE, "libpgca_hip.so")
 NT, NN, TN = 0, 1, 2
 EPI_NONE, EPI_GELU_NEW, EPI_QUICK_GELU, EPI_RELU, EPI_TANH = 0, 1, 2, 3, 4
 EPI_DGELU_NEW, EPI_DRELU, EPI_DTANH, EPI_ROWSTATS, EPI_DLOGITS, EPI_DQUICK_GELU = 5, 6, 7, 8, 9, 10
+EPI_GELU_NEW_D, EPI_MUL_AUX = 11, 12
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
@@ -114,7 +115,7 @@ _SIGS = {
 }
 EXPORTS = ["pgca_version", "pgca_last_error", "pgca_sizeof_gemm_args", "pgca_sizeof_skinny_args",
            "pgca_gemm_skinny_workspace"] + list(_SIGS)
-ABI_VERSION = 302  # include/pgca_hip.h PGCA_ABI_VERSION
+ABI_VERSION = 303  # include/pgca_hip.h PGCA_ABI_VERSION
 
 _lib = None
 

@@ -713,3 +713,37 @@ def test_dgelu_gemm_leaves_bias_gradient_partials(hip, tile, shape):
     close(out.float(), want, 2e-2, "dpre itself")
     with pytest.raises(RuntimeError, match="colsum_part"):
         hip.gemm(a, w, M, N, K, hip.NT, out_bf16=out, colsum_part=part)
+
+
+@pytest.mark.parametrize("shape", [(512, 512, 256), (300, 200, 128), (130, 520, 192)])
+def test_gelu_with_saved_derivative_and_multiply_backward(hip, tile, shape):
+    """The GPT-2 MLP pair that evaluates the sigmoid once: forward ``EPI_GELU_NEW_D`` writes gelu_new(pre) and, as aux_out,
+    gelu_new'(pre); backward ``EPI_MUL_AUX`` multiplies the data gradient by that saved derivative and leaves the bias-gradient
+    column sums - together the same numbers as GELU_NEW + DGELU_NEW (HF NewGELUActivation, activations.py:59-66)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M * 3 + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dev()).bfloat16()
+    w = (torch.randn(K, N, generator=g) * 0.2).to(dev()).bfloat16()            # NN: pre = x @ w + b
+    bias = torch.randn(N, generator=g).to(dev())
+    act = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    der = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    hip.gemm(x, w, M, N, K, hip.NN, epilogue=hip.EPI_GELU_NEW_D, bias=bias, out_bf16=act, aux_out=der)
+    pre = (x.float() @ w.float() + bias).requires_grad_()
+    y = R.gelu_new(pre)
+    y.sum().backward()
+    close(act, y.detach(), 1.0 / 100, "gelu_new")
+    close(der, pre.grad, 1.0 / 100, "gelu_new' saved by the forward")
+    # backward: dpre = (go @ w2^t) * gelu'(pre), column sums per 64-row block
+    go = (torch.randn(M, 64, generator=g) * 0.5).to(dev()).bfloat16()
+    w2 = (torch.randn(N, 64, generator=g) * 0.5).to(dev()).bfloat16()           # NT: go @ w2^t
+    nbr = (M + 63) // 64
+    dpre = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    part = torch.full((nbr, N), float("nan"), device=dev())
+    hip.gemm(go, w2, M, N, 64, hip.NT, epilogue=hip.EPI_MUL_AUX, aux_in=der, out_bf16=dpre, colsum_part=part)
+    want = (go.float() @ w2.float().t()) * der.float()
+    close(dpre.float(), want, 1.0 / 100, "dpre")
+    assert torch.isfinite(part).all()
+    close(part.double().sum(0), want.double().sum(0), 2e-3, "bias gradient from the same pass")
+    old = torch.empty_like(dpre)                                                   # and against the two-sigmoid pair
+    hip.gemm(go, w2, M, N, 64, hip.NT, epilogue=hip.EPI_DGELU_NEW, aux_in=pre.detach().bfloat16(), out_bf16=old)
+    close(dpre.float(), old.float(), 3e-2, "MUL_AUX vs DGELU_NEW")
