@@ -303,6 +303,8 @@ class GptTrunk:
     replayed in the backward; without ``drop`` they are the identity (eval semantics).
     """
 
+    GELU_PAIR = os.environ.get("PGCA_GELU_PAIR", "1") != "0"   # A/B switch: 0 = evaluate the sigmoid again in the backward
+
     def __init__(self, store: ParamStore, prefix: str, arch: GptArch, ws: Workspace, tag: str):
         self.arch, self.ws, self.tag = arch, ws, tag
         seg = store.seg_of(prefix + ".ln_f.weight")
@@ -371,7 +373,8 @@ class GptTrunk:
             # training: the epilogue has the sigmoid of gelu_new in registers and leaves gelu_new'(pre) for the backward, whose
             # data-gradient GEMM then only multiplies (EPI_MUL_AUX) instead of evaluating the sigmoid a second time
             pre = self._buf(k + "pre", (M, I), BF16) if save else None
-            hip.gemm(ln2, P["wfc"].b, M, I, H, hip.NN, epilogue=hip.EPI_GELU_NEW_D if save else hip.EPI_GELU_NEW,
+            hip.gemm(ln2, P["wfc"].b, M, I, H, hip.NN,
+                     epilogue=hip.EPI_GELU_NEW_D if (save and self.GELU_PAIR) else hip.EPI_GELU_NEW,
                      bias=P["bfc"].w, out_bf16=act, aux_out=pre)
             hn = self._buf(f"l{li + 1}.hin", (M, H), F32) if save else hm
             hip.gemm(act, P["wpr"].b, M, H, I, hip.NN, bias=P["bpr"].w, residual=hm, out_f32=hn,
@@ -515,8 +518,9 @@ class GptTrunk:
             # pass over the M x 4H matrix
             nbr = (M + 63) // 64
             dpre_cs = self._buf("dpre_colsum", (nbr, I), F32)
-            hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_MUL_AUX, aux_in=s["pre"], out_bf16=dpre,
-                     colsum_part=dpre_cs)      # s["pre"] holds gelu_new'(pre-activation) (forward: EPI_GELU_NEW_D)
+            # s["pre"] holds gelu_new'(pre-activation) when the forward ran EPI_GELU_NEW_D, else the pre-activation
+            hip.gemm(g_bf, P["wpr"].b, M, I, H, hip.NT, epilogue=hip.EPI_MUL_AUX if self.GELU_PAIR else hip.EPI_DGELU_NEW,
+                     aux_in=s["pre"], out_bf16=dpre, colsum_part=dpre_cs)
             hip.colsum_finish(dpre_cs, nbr, I, P["bfc"].g, accumulate=True)
             wgrads = [(s["act"], g_bf, I, H, M, P["wpr"].g)]   # the layer's four weight gradients go out together
             dln = self._buf("dln", (M, H), BF16)
