@@ -239,8 +239,10 @@ __global__ __launch_bounds__(TNT, 4) void attn_fwd_tiled_kernel(const bf16_t* __
 }
 
 // ------------------------------------------------------------------------------------ backward
-template <int NQB>
-__global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __restrict__ qkv,
+// ALIAS (one-block sequences only): the dS^t image lives where V and Q were - both are dead once phase A is over - so
+// a workgroup needs 75 KiB of LDS instead of 109 and two of them share a CU (registers capped at 128 for that).
+template <int NQB, bool ALIAS>
+__global__ __launch_bounds__(TNT, ALIAS ? 4 : 2) void attn_bwd_tiled_kernel(const bf16_t* __restrict__ qkv,
                                                                 const bf16_t* __restrict__ O,
                                                                 const bf16_t* __restrict__ dO,
                                                                 const float* __restrict__ lse_i,
@@ -252,12 +254,13 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
   unsigned char* Vs = smem + TILE_QKV;
   unsigned char* Qs = smem + 2 * TILE_QKV;
   unsigned char* dOs = smem + 3 * TILE_QKV;
-  unsigned char* dSs = smem + 4 * TILE_QKV;                        // dS^t image [128 keys][128 queries]
-  float* lses = reinterpret_cast<float*>(dSs + TILE_P);            // [NQB * 128]
+  static_assert(!ALIAS || (NQB == 1 && TILE_P <= 2 * TILE_QKV), "aliasing needs a single (key, query) pair");
+  unsigned char* dSs = ALIAS ? Vs : smem + 4 * TILE_QKV;           // dS^t image [128 keys][128 queries]
+  float* lses = reinterpret_cast<float*>(smem + 4 * TILE_QKV + (ALIAS ? 0 : TILE_P));  // [NQB * 128]
   float* dels = lses + NQB * TB;                                   // [NQB * 128]
   unsigned char* kms = reinterpret_cast<unsigned char*>(dels + NQB * TB);  // [128]
 
-  const int h = blockIdx.x, b = blockIdx.y;
+  const int b = blockIdx.y;
   const int row0 = cu ? cu[b] : b * Sp;  // packed rows: see the forward
   if (cu) S = min(S, cu[b + 1] - row0);
   if (S <= 0) return;
@@ -265,22 +268,47 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int g = lane >> 4, i16 = lane & 15;
+
+  // A workgroup's memory latency is hidden by at most one other workgroup on its CU (none when S > 128): the first
+  // (key block, query block) pair - K, V, Q, dO tiles - is REQUESTED together with the row constants' inputs (O rows for
+  // delta, lse) into registers and stored to LDS afterwards: one HBM round trip in front of the first MFMA instead of
+  // three.  With packed sequences (mean length 72 of 128) most workgroups have exactly one pair.
+  constexpr int NLSE = (NQB * TB + TNT - 1) / TNT;
+  const int h = blockIdx.x;
   const bf16_t* base = qkv + (size_t)row0 * ld + h * DH;
   const bf16_t* obase = O + (size_t)row0 * H + h * DH;
   const bf16_t* dobase = dO + (size_t)row0 * H + h * DH;
   bf16_t* dbase_g = dqkv + (size_t)row0 * ld + h * DH;
-
-  // One workgroup per CU (108 KiB of LDS) means nobody hides this workgroup's memory latency: the first (key block,
-  // query block) pair's four tiles are REQUESTED here, together with the row constants below, and stored to LDS after
-  // them - one HBM round trip in front of the first MFMA instead of three (row constants, K/V, Q/dO).  With packed
-  // sequences (mean length 72 of 128) most workgroups have exactly one pair.
-  StageRegs pk, pv, pq, pdo;
+  StageRegs pk, pv, pq, pdo, po;
+  float plse[NLSE];
   stage_load(pk, base + H, ld, 0, S, t);
   stage_load(pv, base + 2 * H, ld, 0, S, t);
   stage_load(pq, base, ld, 0, S, t);
   stage_load(pdo, dobase, H, 0, S, t);
-  // row constants of every query: lse and delta[q] = sum_d dO[q,d] O[q,d] (8 lanes per row)
-  for (int idx = t; idx < NQB * TB * 8; idx += TNT) {
+  stage_load(po, obase, H, 0, S, t);
+#pragma unroll
+  for (int j = 0; j < NLSE; ++j) {
+    const int i = t + TNT * j;
+    plse[j] = i < S ? lse_i[((size_t)b * heads + h) * Sp + i] : 0.f;
+  }
+
+  // row constants of every query: lse and delta[q] = sum_d dO[q,d] O[q,d] (8 lanes per row).  Rows of the first query
+  // block come from the requested registers (stage_load's (row, chunk) map is this loop's), later blocks from memory.
+#pragma unroll
+  for (int i = 0; i < 1024 / TNT; ++i) {
+    const int idx = t + TNT * i;
+    const int row = idx >> 3, c = idx & 7;
+    const bf16x8 a = __builtin_bit_cast(bf16x8, po.v[i]);
+    const bf16x8 gg = __builtin_bit_cast(bf16x8, pdo.v[i]);
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) d += (float)a[e] * (float)gg[e];
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    d += __shfl_xor(d, 4);
+    if (c == 0) dels[row] = d;
+  }
+  for (int idx = t + 1024; idx < NQB * TB * 8; idx += TNT) {
     const int row = idx >> 3, c = idx & 7;
     float d = 0.f;
     if (row < S) {
@@ -294,7 +322,9 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
     d += __shfl_xor(d, 4);
     if (c == 0) dels[row] = d;
   }
-  for (int i = t; i < NQB * TB; i += TNT) lses[i] = i < S ? lse_i[((size_t)b * heads + h) * Sp + i] : 0.f;
+#pragma unroll
+  for (int j = 0; j < NLSE; ++j)
+    if (t + TNT * j < NQB * TB) lses[t + TNT * j] = plse[j];
 
   f32x4 dq[NQB][4];
 #pragma unroll
@@ -303,7 +333,7 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
     for (int nt = 0; nt < 4; ++nt) dq[qb][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const float scale = 0.125f;
-  const int nblk = (S + TB - 1) / TB;  // key blocks == query blocks (<= NQB)
+  const int nblk = NQB == 1 ? 1 : (S + TB - 1) / TB;  // key blocks == query blocks (<= NQB; S > 0 here)
   unsigned char* mine = dSs + (16 * w) * PS;  // this wave's own 16 rows of the dS^t image (also its store staging)
 
   for (int kb = 0; kb < nblk; ++kb) {
@@ -348,9 +378,8 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
         const int nqt = min(8, (S - q0 + 15) >> 4);          // 16-query tiles with a real row
         // on the diagonal block queries below this wave's first key see none of its keys
         const int mi_lo = (causal && qb == kb) ? w : 0;
-        if (has_keys) {
-#pragma unroll 1
-          for (int s = 0; s < 4; ++s) {
+        u32x2 dsp[ALIAS ? 8 : 1];
+        auto phase_a = [&](const int s) {
             float pd[2][4], ds[2][4];
             if (2 * s < nqt && 2 * s + 1 >= mi_lo) {
               f32x4 sa[2], da[2];
@@ -401,13 +430,30 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
               u32x2 pk;
               pk[0] = pack2(ds[tt][0], ds[tt][1]);
               pk[1] = pack2(ds[tt][2], ds[tt][3]);
-              *reinterpret_cast<u32x2*>(mine + i16 * PS + ((2 * s + tt) * 16 + g * 4) * 2) = pk;
+              if constexpr (ALIAS) dsp[2 * s + tt] = pk;   // V / Q are still being read: held until the barrier
+              else *reinterpret_cast<u32x2*>(mine + i16 * PS + ((2 * s + tt) * 16 + g * 4) * 2) = pk;
             }
+        };
+        if (has_keys) {
+          if constexpr (ALIAS) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) phase_a(s);
+          } else {
+#pragma unroll 1
+            for (int s = 0; s < 4; ++s) phase_a(s);
           }
         } else {  // no real key in this wave's rows: the dQ product must read zeros there
 #pragma unroll
+          for (int mi = 0; mi < 8; ++mi) {
+            if constexpr (ALIAS) dsp[mi] = (u32x2){0u, 0u};
+            else *reinterpret_cast<u32x2*>(mine + i16 * PS + (mi * 16 + g * 4) * 2) = (u32x2){0u, 0u};
+          }
+        }
+        if constexpr (ALIAS) {
+          __syncthreads();  // every wave is done with V and Q: their space takes the dS^t image
+#pragma unroll
           for (int mi = 0; mi < 8; ++mi)
-            *reinterpret_cast<u32x2*>(mine + i16 * PS + (mi * 16 + g * 4) * 2) = (u32x2){0u, 0u};
+            *reinterpret_cast<u32x2*>(mine + i16 * PS + (mi * 16 + g * 4) * 2) = dsp[mi];
         }
         __syncthreads();
         // ---- phase B: dQ[q][d] += dS[q][key] K[key][d] for this wave's 16 queries of the block
@@ -471,16 +517,21 @@ __global__ __launch_bounds__(TNT, 2) void attn_bwd_tiled_kernel(const bf16_t* __
 constexpr size_t TFWD_LDS = 2 * TILE_QKV + TB;
 constexpr size_t tbwd_lds(int nqb) { return 4 * TILE_QKV + TILE_P + 2 * (size_t)nqb * TB * sizeof(float) + TB; }
 
+constexpr size_t TBWD_ALIAS_LDS = 4 * TILE_QKV + 2 * (size_t)TB * sizeof(float) + TB;
+
+// One-block sequences (S <= 128: every training shape) take the aliased layout, two workgroups per CU.
 template <int NQB>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, const int32_t* key_mask, int B,
                int S, int heads, int causal, void* dqkv, Drop drop, const int32_t* cu, hipStream_t s) {
-  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_bwd_tiled_kernel<NQB>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)tbwd_lds(NQB));
+  constexpr bool ALIAS = NQB == 1;
+  constexpr size_t lds = ALIAS ? TBWD_ALIAS_LDS : tbwd_lds(NQB);
+  static const hipError_t attr = hipFuncSetAttribute((const void*)attn_bwd_tiled_kernel<NQB, ALIAS>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (attr != hipSuccess) {
     set_error("attention (tiled backward): cannot raise dynamic LDS limit");
     return PGCA_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(attn_bwd_tiled_kernel<NQB>, dim3(heads, B), dim3(TNT), tbwd_lds(NQB), s, (const bf16_t*)qkv,
+  hipLaunchKernelGGL((attn_bwd_tiled_kernel<NQB, ALIAS>), dim3(heads, B), dim3(TNT), lds, s, (const bf16_t*)qkv,
                      (const bf16_t*)out, (const bf16_t*)dout, lse, key_mask, S, heads, causal, (bf16_t*)dqkv, drop, cu, S);
   return check_launch("pgca_attention_bwd(tiled)");
 }

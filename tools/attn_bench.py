@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--causal", type=int, default=1)
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--packed", type=int, default=0, help="1: packed rows (cu offsets, the training layout), lengths 16..S")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     hip.load()
@@ -37,6 +38,12 @@ def main():
     lse = torch.empty(B, heads, S, device=dev)
     dqkv = torch.empty(B * S, 3 * H, dtype=torch.bfloat16, device=dev)
     d = hip.drop_args(77, args.drop)
+    cu = None
+    if args.packed:
+        cu = torch.zeros(B + 1, dtype=torch.int32)
+        cu[1:] = torch.cumsum(lens, 0)
+        cu = cu.to(dev)
+        mask = None
 
     def timeit(fn):
         for _ in range(3):
@@ -50,12 +57,13 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / args.iters
 
-    tf = timeit(lambda: hip.attention_fwd(qkv, mask, B, S, heads, bool(args.causal), out, lse, drop=d))
-    tb = timeit(lambda: hip.attention_bwd(qkv, out, dout, lse, mask, B, S, heads, bool(args.causal), dqkv, drop=d))
-    fl = 4.0 * B * heads * S * S * 64
-    byt_f = B * S * H * 2 * 4 + B * heads * S * 4
-    byt_b = B * S * H * 2 * (3 + 1 + 1 + 3)
-    print(f"tiled={os.environ.get('PGCA_ATTN_TILED', '0')} B={B} heads={heads} S={S} causal={args.causal} drop={args.drop}: "
+    tf = timeit(lambda: hip.attention_fwd(qkv, mask, B, S, heads, bool(args.causal), out, lse, drop=d, cu=cu))
+    tb = timeit(lambda: hip.attention_bwd(qkv, out, dout, lse, mask, B, S, heads, bool(args.causal), dqkv, drop=d, cu=cu))
+    rows = int(lens.sum()) if args.packed else B * S
+    fl = 4.0 * heads * 64 * (float((lens.double() ** 2).sum()) if args.packed else B * S * S)
+    byt_f = rows * H * 2 * 4 + rows * heads * 4
+    byt_b = rows * H * 2 * (3 + 1 + 1 + 3)
+    print(f"packed={args.packed} tiled={os.environ.get('PGCA_ATTN_TILED', '0')} B={B} heads={heads} S={S} causal={args.causal} drop={args.drop}: "
           f"fwd {tf:7.1f} us ({fl / tf / 1e6:6.1f} TF/s, {byt_f / tf / 1e6:5.2f} TB/s)   "
           f"bwd {tb:7.1f} us ({2.5 * fl / tb / 1e6:6.1f} TF/s, {byt_b / tb / 1e6:5.2f} TB/s)")
 
