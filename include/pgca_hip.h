@@ -36,7 +36,7 @@ typedef enum pgca_status {
   PGCA_ERR_LAUNCH = -2   /* hipLaunch failed; see pgca_last_error() */
 } pgca_status;
 
-#define PGCA_ABI_VERSION 303 /* bumped whenever a signature or struct layout below changes */
+#define PGCA_ABI_VERSION 304 /* bumped whenever a signature or struct layout below changes */
 int pgca_version(void);        /* == PGCA_ABI_VERSION of the header the library was built from */
 int pgca_sizeof_gemm_args(void); /* sizeof(pgca_gemm_args) as compiled: bindings compare it with their own layout */
 const char* pgca_last_error(void);
@@ -289,6 +289,26 @@ int pgca_image_preprocess(const uint8_t* images, int32_t B, int32_t H, int32_t W
                           const int32_t* xcoef, int32_t xk, const int32_t* ybounds, const int32_t* ycoef, int32_t yk,
                           float mean0, float mean1, float mean2, float std0, float std1, float std2, uint8_t* tmp,
                           uint8_t* resized_u8, float* out, void* stream);
+
+/* TRAINING transform of the reference's loader on the device (data/preprocessing.py:52-70, augment=True:
+ * RandomResizedCrop(S, scale (0.8, 1), ratio (0.75, 1.33)) -> RandomHorizontalFlip -> ColorJitter(0.2, 0.2, 0.2, 0.1) ->
+ * RandomRotation(5) -> ToTensor -> Normalize), BIT-EXACT with torchvision's PIL backend GIVEN the random draws, which
+ * stay on the host (pgca_amd.input.draw_train_params restates torchvision's get_params).  Per image b:
+ *   params int32 [B, 20]: crop box i, j, h, w (top, left, height, width; inside the H x W image) | flip 0/1 |
+ *     the four ColorJitter operations in their drawn order (0 brightness, 1 contrast, 2 saturation, 3 hue) |
+ *     hue turn = uint8(hue_factor * 255) | rotate 0/1 (0: angle % 360 == 0, PIL copies) |
+ *     a0 a1 a2 a3 a4 a5: Geometry.c affine_fixed's 16.16 integers of the output->input map | 3 unused;
+ *   factors f32 [B, 3]: brightness, contrast, saturation (Blend.c alpha);
+ *   x/ybounds int32 [B, S, 2], x/ycoef int32 [B, S, xk / yk]: resample taps for w_b -> S and h_b -> S (rows padded with
+ *     zeros to the batch's widest table).
+ * tmp u8 [B, H, S, 3] and resized_u8 u8 [B, S, S, 3] are scratch (the latter returns the cropped + resized image);
+ * aug_u8 (optional) u8 [B, S, S, 3] receives the augmented image before ToTensor; out f32 [B, 3, S, S].
+ * The jitter + rotation stage keeps one S x S x 3 image in LDS: S <= 230 (every shipped config uses 224). */
+int pgca_image_train_transform(const uint8_t* images, int32_t B, int32_t H, int32_t W, int32_t S, const int32_t* params,
+                               const float* factors, const int32_t* xbounds, const int32_t* xcoef, int32_t xk,
+                               const int32_t* ybounds, const int32_t* ycoef, int32_t yk, float mean0, float mean1,
+                               float mean2, float std0, float std1, float std2, uint8_t* tmp, uint8_t* resized_u8,
+                               uint8_t* aug_u8, float* out, void* stream);
 
 /* ------------------------------------------------------------------ sequence reduce + losses */
 /* tok_lp f32 [nrows] are token log-probs of the COMPACT rows; row r belongs to sequence seq_of_row[r].

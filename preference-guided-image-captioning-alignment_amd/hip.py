@@ -87,6 +87,8 @@ _SIGS = {
     "pgca_patchify": [_vp, _i32, _i32, _i32, _i32, _vp, _vp],
     "pgca_image_preprocess": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _f32, _f32, _f32, _f32,
                               _vp, _vp, _vp, _vp],
+    "pgca_image_train_transform": [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f32, _f32, _f32,
+                                   _f32, _f32, _f32, _vp, _vp, _vp, _vp, _vp],
     "pgca_vit_assemble": [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "pgca_vit_assemble_bwd": [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp],
     "pgca_seq_reduce": [_vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp],
@@ -115,7 +117,7 @@ _SIGS = {
 }
 EXPORTS = ["pgca_version", "pgca_last_error", "pgca_sizeof_gemm_args", "pgca_sizeof_skinny_args",
            "pgca_gemm_skinny_workspace"] + list(_SIGS)
-ABI_VERSION = 303  # include/pgca_hip.h PGCA_ABI_VERSION
+ABI_VERSION = 304  # include/pgca_hip.h PGCA_ABI_VERSION
 
 _lib = None
 
@@ -361,6 +363,14 @@ def image_preprocess(images_u8, B, H, W, S, xbounds, xcoef, ybounds, ycoef, mean
     _check(load().pgca_image_preprocess(_p(images_u8), B, H, W, S, _p(xbounds), _p(xcoef), xcoef.shape[1], _p(ybounds),
                                         _p(ycoef), ycoef.shape[1], mean[0], mean[1], mean[2], std[0], std[1], std[2],
                                         _p(tmp), _p(resized_u8), _p(out), _stream()), "pgca_image_preprocess")
+
+
+def image_train_transform(images_u8, B, H, W, S, params, factors, xbounds, xcoef, ybounds, ycoef, mean, std, tmp, resized_u8,
+                          out, aug_u8=None):
+    _check(load().pgca_image_train_transform(_p(images_u8), B, H, W, S, _p(params), _p(factors), _p(xbounds), _p(xcoef),
+                                             xcoef.shape[-1], _p(ybounds), _p(ycoef), ycoef.shape[-1], mean[0], mean[1],
+                                             mean[2], std[0], std[1], std[2], _p(tmp), _p(resized_u8), _p(aug_u8), _p(out),
+                                             _stream()), "pgca_image_train_transform")
 
 
 def vit_assemble(patch_embeds, cls, pos, B, T, H, x):

@@ -61,8 +61,8 @@ class GpuImageProcessor:
     """The reference's ``ImageProcessor.val_transform`` (data/preprocessing.py:44-48,78; also its training transform with
     ``augment=False``, :70) on the device: decoded RGB uint8 ``[B, H, W, 3]`` (or a list of ``[H, W, 3]`` images of any
     sizes) -> ``Resize((S, S))`` -> ``ToTensor`` -> ``Normalize(mean, std)`` -> f32 ``[B, 3, S, S]``, bit-exact with the host
-    path (``pgca_image_preprocess``).  The random augmentations of the training transform (preprocessing.py:53-68) stay
-    with the host loader."""
+    path (``pgca_image_preprocess``).  ``process_train_batch`` is the training transform WITH the random augmentations
+    (preprocessing.py:53-68): the draws are made on the host, the pixels are worked on the device."""
 
     def __init__(self, image_size: int = 224, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225), device=None):
         import numpy as np
@@ -74,6 +74,7 @@ class GpuImageProcessor:
             raise ValueError("std evaluated to zero after conversion to float32, leading to division by zero.")
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._tables = {}
+        self._host_tables = {}
 
     def _table(self, n_in: int):
         t = self._tables.get(n_in)
@@ -100,6 +101,71 @@ class GpuImageProcessor:
         hip.image_preprocess(x, B, H, W, S, xb, xk, yb, yk, self.mean, self.std, tmp, out, resized_u8=res)
         return (out, res) if return_resized else out
 
+    def _batched_tables(self, sizes):
+        """Tap tables of ``size_b -> S`` for every image of the batch, rows zero-padded to the widest one."""
+        import numpy as np
+        S = self.image_size
+        tabs = []
+        for n in sizes:
+            t = self._host_tables.get(n)
+            if t is None:
+                t = self._host_tables[n] = resample_tables(n, S)
+            tabs.append(t)
+        kmax = max(t[1].shape[1] for t in tabs)
+        bounds = np.stack([t[0] for t in tabs])
+        coef = np.zeros((len(tabs), S, kmax), np.int32)
+        for b, t in enumerate(tabs):
+            coef[b, :, :t[1].shape[1]] = t[1]
+        return torch.from_numpy(bounds).to(self.device), torch.from_numpy(coef).to(self.device)
+
+    def process_train_batch(self, images: torch.Tensor, params=None, generator: torch.Generator = None,
+                            out: torch.Tensor = None, return_augmented: bool = False):
+        """The reference's ``train_transform`` with ``augment=True`` (data/preprocessing.py:52-70) on the device:
+        RandomResizedCrop -> RandomHorizontalFlip -> ColorJitter -> RandomRotation(5) -> ToTensor -> Normalize, bit-exact
+        with torchvision's PIL backend given the draws.  ``images`` uint8 [B, H, W, 3]; ``params``: one dict per image
+        as ``draw_train_params`` returns them (drawn here from ``generator`` when omitted).  Returns f32 [B, 3, S, S]
+        (and the augmented uint8 images [B, S, S, 3] with ``return_augmented``)."""
+        import numpy as np
+        from . import hip
+        if images.dtype != torch.uint8 or images.dim() != 4 or images.shape[-1] != 3:
+            raise ValueError(f"Expected uint8 images of shape (B, H, W, 3), got {images.dtype} {tuple(images.shape)}")
+        B, H, W, _ = images.shape
+        S = self.image_size
+        if params is None:
+            params = [draw_train_params(H, W, generator) for _ in range(B)]
+        if len(params) != B:
+            raise ValueError(f"{len(params)} parameter sets for {B} images")
+        ints = np.zeros((B, TRAIN_PARAM_INTS), np.int32)
+        fac = np.zeros((B, 3), np.float32)
+        for b, p in enumerate(params):
+            i, j, h, w = (int(v) for v in p["box"])
+            if not (0 <= i and 0 <= j and 0 < h and 0 < w and i + h <= H and j + w <= W):
+                raise ValueError(f"crop box {p['box']} outside the {H} x {W} image")
+            order = [int(v) for v in p["order"]]
+            if sorted(order) != [0, 1, 2, 3]:
+                raise ValueError(f"order must be a permutation of 0..3, got {p['order']}")
+            rot = rotate_fixed_coeffs(float(p["angle"]), S, S)
+            ints[b, :4] = (i, j, h, w)
+            ints[b, 4] = 1 if p["flip"] else 0
+            ints[b, 5:9] = order
+            ints[b, 9] = int(float(p["hue"]) * 255) % 256     # torchvision: np.array(hue * 255).astype(np.uint8)
+            if rot is not None:
+                ints[b, 10] = 1
+                ints[b, 11:17] = rot
+            fac[b] = (p["brightness"], p["contrast"], p["saturation"])
+        x = images.to(self.device, non_blocking=True).contiguous()
+        xb, xk = self._batched_tables([int(r[3]) for r in ints])
+        yb, yk = self._batched_tables([int(r[2]) for r in ints])
+        dev = self.device
+        tmp = torch.empty((B, H, S, 3), dtype=torch.uint8, device=dev)
+        res = torch.empty((B, S, S, 3), dtype=torch.uint8, device=dev)
+        aug = torch.empty((B, S, S, 3), dtype=torch.uint8, device=dev) if return_augmented else None
+        if out is None:
+            out = torch.empty((B, 3, S, S), dtype=torch.float32, device=dev)
+        hip.image_train_transform(x, B, H, W, S, torch.from_numpy(ints).to(dev), torch.from_numpy(fac).to(dev), xb, xk, yb,
+                                  yk, self.mean, self.std, tmp, res, out, aug_u8=aug)
+        return (out, aug) if return_augmented else out
+
     def __call__(self, images):
         """A uint8 batch tensor, or a list of uint8 ``[H, W, 3]`` images of mixed sizes (grouped by size, order kept)."""
         if isinstance(images, torch.Tensor):
@@ -114,6 +180,81 @@ class GpuImageProcessor:
             res = self.process_batch(batch)
             out[torch.as_tensor(idx, device=self.device)] = res
         return out
+
+
+# ----------------------------------------------------------------------------------------------- training transform
+TRAIN_PARAM_INTS = 20       # include/pgca_hip.h pgca_image_train_transform
+
+
+def _fix16(v: float) -> int:
+    v = v * 65536.0 + 0.5                      # Pillow Geometry.c FIX = FLOOR(v * 65536.0 + 0.5)
+    return int(math.floor(v)) if v < 0 else int(v)
+
+
+def rotate_fixed_coeffs(angle: float, w: int, h: int):
+    """``PIL.Image.rotate(angle, NEAREST, expand=False, center=None)``: the output->input affine matrix as Pillow builds it
+    (cos / sin rounded to 15 digits, centre (w/2, h/2)) turned into Geometry.c ``affine_fixed``'s six 16.16 integers
+    (a0, a1, a2, a3, a4, a5); None when ``angle % 360 == 0`` (Pillow returns a copy)."""
+    angle = angle % 360.0
+    if angle == 0:
+        return None
+    cx, cy = w / 2.0, h / 2.0
+    a = -math.radians(angle)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    m[2], m[5] = m[0] * -cx + m[1] * -cy + m[2], m[3] * -cx + m[4] * -cy + m[5]
+    m[2] += cx
+    m[5] += cy
+    return (_fix16(m[0]), _fix16(m[1]), _fix16(m[2] + m[0] * 0.5 + m[1] * 0.5),
+            _fix16(m[3]), _fix16(m[4]), _fix16(m[5] + m[3] * 0.5 + m[4] * 0.5))
+
+
+def draw_train_params(height: int, width: int, generator: torch.Generator = None, scale=(0.8, 1.0), ratio=(0.75, 1.33),
+                      flip_p: float = 0.5, brightness: float = 0.2, contrast: float = 0.2, saturation: float = 0.2,
+                      hue: float = 0.1, degrees: float = 5.0) -> dict:
+    """One image's random draws of the reference's training transform (data/preprocessing.py:53-68), made with the torch
+    RNG calls torchvision makes and in its order: ``RandomResizedCrop.get_params`` (up to ten (area, log-ratio) tries, then
+    the central-crop fallback), ``RandomHorizontalFlip`` (``torch.rand(1) < p``), ``ColorJitter.get_params``
+    (``randperm(4)`` then the four uniform factors), ``RandomRotation.get_params``.  torchvision is not installed here:
+    restated from its published source, so the DRAW ORDER is unpinned; the pixel work given these draws is pinned
+    against Pillow (tests/test_image_cpu.py, tests/test_image_gpu.py)."""
+    g = generator
+
+    def uniform(lo, hi):
+        return float(torch.empty(1).uniform_(float(lo), float(hi), generator=g))
+
+    area = height * width
+    log_ratio = torch.log(torch.tensor(ratio))
+    box = None
+    for _ in range(10):
+        target_area = area * uniform(scale[0], scale[1])
+        aspect = float(torch.exp(torch.empty(1).uniform_(float(log_ratio[0]), float(log_ratio[1]), generator=g)))
+        w = int(round(math.sqrt(target_area * aspect)))
+        h = int(round(math.sqrt(target_area / aspect)))
+        if 0 < w <= width and 0 < h <= height:
+            i = int(torch.randint(0, height - h + 1, size=(1,), generator=g))
+            j = int(torch.randint(0, width - w + 1, size=(1,), generator=g))
+            box = (i, j, h, w)
+            break
+    if box is None:                                     # fallback to the central crop
+        in_ratio = float(width) / float(height)
+        if in_ratio < min(ratio):
+            w = width
+            h = int(round(w / min(ratio)))
+        elif in_ratio > max(ratio):
+            h = height
+            w = int(round(h * max(ratio)))
+        else:
+            w, h = width, height
+        box = ((height - h) // 2, (width - w) // 2, h, w)
+    flip = bool(torch.rand(1, generator=g) < flip_p)
+    order = [int(v) for v in torch.randperm(4, generator=g)]
+    b = uniform(max(0.0, 1.0 - brightness), 1.0 + brightness)
+    c = uniform(max(0.0, 1.0 - contrast), 1.0 + contrast)
+    sfac = uniform(max(0.0, 1.0 - saturation), 1.0 + saturation)
+    hfac = uniform(-hue, hue)
+    angle = uniform(-degrees, degrees)
+    return {"box": box, "flip": flip, "order": order, "brightness": b, "contrast": c, "saturation": sfac, "hue": hfac,
+            "angle": angle}
 
 
 class TokenisedCaptionCache:

@@ -225,10 +225,32 @@ class ContrastiveStep:
         self.ntx = NTXentEngine(ws, store.arch.proj_dim, temperature)
         self.dp = dp if (dp is not None and global_negatives and dp.world > 1) else None
 
+    _processors: dict = {}
+
+    @staticmethod
+    def _device_images(batch: dict, device) -> torch.Tensor:
+        """A loader that hands over DECODED images (``image`` uint8 [B, H, W, 3]) gets the reference's image transform on
+        the device (input.GpuImageProcessor, bit-exact with the host path): ``augment`` true -> the training transform
+        with the random augmentations (data/preprocessing.py:52-70; draws from ``augment_params`` or the torch global RNG,
+        as torchvision in a loader worker), otherwise the validation transform (:44-48).  ``image_size`` defaults to 224."""
+        from .input import GpuImageProcessor
+        size = int(batch.get("image_size", 224))
+        key = (str(device), size)
+        proc = ContrastiveStep._processors.get(key)
+        if proc is None:
+            proc = ContrastiveStep._processors[key] = GpuImageProcessor(size, device=device)
+        if batch.get("augment", False):
+            return proc.process_train_batch(batch["image"], batch.get("augment_params"))
+        return proc.process_batch(batch["image"])
+
     @staticmethod
     def prepare(batch: dict, device) -> dict:
         mask = (batch["caption_mask"] != 0).to(I32).to(device, non_blocking=True).contiguous()
-        return {"image": batch["image"].to(device, F32, non_blocking=True),
+        if batch["image"].dtype == torch.uint8:
+            image = ContrastiveStep._device_images(batch, device)
+        else:
+            image = batch["image"].to(device, F32, non_blocking=True)
+        return {"image": image,
                 "ids": batch["caption_ids"].to(device, I64, non_blocking=True),
                 "mask": mask, "pack": make_row_pack(mask)}
 
