@@ -22,7 +22,10 @@ import os
 import sys
 import time
 
-import torch
+# dmabuf IPC (RCCL across the ranks of a node needs it on this pool); must be in place before the HIP runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
