@@ -244,7 +244,9 @@ def main():
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="A/B: keep the grouped weight-gradient launches on the main stream (round-1 behaviour)")
     ap.add_argument("--ref-side-stream", action="store_true",
-                    help="run the frozen reference-policy forward on a second HIP stream, concurrently with the policy's")
+                    help="run the frozen reference-policy forward on a second HIP stream, concurrently with the policy's "
+                         "(+1.4 %% pairs/s; not the default because two GEMMs sharing the chip make the per-launch "
+                         "duration behind `roofline` meaningless - DESIGN section 5)")
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="pgca_set_option dispatch knob (e.g. gemm_stagger=8); repeatable")
     ap.add_argument("--trainable-vision", action="store_true",

@@ -229,6 +229,45 @@ def test_packed_dpo_step_equals_padded(S, lens, train, ref_free, holes):
                 assert _cos(a, b) >= 0.99999, key
 
 
+def test_reference_policy_on_its_own_stream_changes_nothing():
+    """The frozen reference policy's forward on a second HIP stream (DPOStep(ref_side_stream=True): its tile tails and
+    epilogues interleave with the policy forward's main loops) against the single-stream order: the reference log-probs
+    are bitwise equal (no atomics on that path), the loss and the policy's results too, gradients up to the f32-atomic
+    summation order of the single-stream run itself."""
+    from pgca_amd.engine import DropoutPlan
+    from pgca_amd.steps import DPOStep, ReferencePolicy
+    model, arch = _model("gpt2-medium")
+    gen = torch.Generator().manual_seed(7)
+    B, S = 3, 128
+    img = torch.randn(B, 3, 224, 224, generator=gen)
+    ids = torch.randint(0, 50257, (2 * B, S), generator=gen)
+    mask = ragged_mask(2 * B, S, [128, 40, 77, 16, 99, 64], ())
+    ids = torch.where(mask.bool(), ids, torch.full_like(ids, 50257))
+    batch = {"image": img, "preferred_ids": ids[:B], "rejected_ids": ids[B:], "preferred_mask": mask[:B],
+             "rejected_mask": mask[B:]}
+    ref = ReferencePolicy(model.store, model.ws)
+    for seg in ref.store.segments.values():
+        seg.fp32.mul_(1.02)
+        seg.ensure_bf16()
+    out = {}
+    for side in (False, True, True):     # twice on the side stream: the second call reuses the stream and the buffers
+        step = DPOStep(model.store, model.ws, model.vision_encoder.tower, model.vision_encoder.head,
+                       model.caption_decoder.engine, beta=0.1, reference_free=False, ref=ref, ref_side_stream=side,
+                       dropout=DropoutPlan(0.1, base_seed=5))
+        p = DPOStep.prepare(batch, model.device)
+        for sg in model.store.trainable_segments():
+            sg.grad.zero_()
+        loss = step.loss_and_grads(p["image"], p["seq"]).clone()
+        torch.cuda.synchronize()
+        out[side] = (loss, model.ws.bufs["pol.seq_lp"][:2 * B].clone(), model.ws.bufs["ref.seq_lp"][:2 * B].clone(),
+                     _grads(model))
+    (l0, p0, r0, g0), (l1, p1, r1, g1) = out[False], out[True]
+    assert torch.equal(r0, r1) and torch.equal(p0, p1) and torch.equal(l0, l1)
+    for name in g0:
+        if float(g0[name].abs().max()) > 0.0:
+            assert _cos(g0[name], g1[name]) >= 0.99999, name
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_packed_contrastive_step_equals_padded(train):
     """Stage-1 step: NT-Xent loss and the gradients of the text tower and both heads, packed vs padded rows."""
